@@ -1,0 +1,140 @@
+/*
+ * zgpu.h -- C ABI of the MI355X (gfx950) batched DEFLATE / CRC-32 / Adler-32
+ * engine that replaces the compression hot path of ryunosinfx/zlib.es.
+ *
+ * The reference is pure JavaScript and has no FFI of its own; its boundary is
+ * the public class API.  Each entry point below names the reference interface
+ * it stands in for (file:line in the reference tree).  A Node.js N-API addon
+ * (zlib.es_amd/js/addon.cc) and a ctypes binding (zlib.es_amd/__init__.py)
+ * bind exactly these symbols.
+ *
+ * Conventions: sizes in bytes; offset arrays have n_units+1 entries; every
+ * function returns ZGPU_OK (0) or a negative ZGPU_E* code unless stated.
+ * "device" pointers are HIP device pointers on the current HIP device.
+ * There is no CPU fallback: without a usable GPU the calls fail with
+ * ZGPU_E_NODEVICE.
+ */
+#ifndef ZGPU_H
+#define ZGPU_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    ZGPU_OK = 0,
+    ZGPU_E_NODEVICE = -1, /* no HIP device / HIP runtime error (see zgpu_last_hip_error) */
+    ZGPU_E_ARG = -2,      /* bad argument ("invalid compression type", rawdeflate.js:121) */
+    ZGPU_E_NOMEM = -3,    /* device or host allocation failed */
+    ZGPU_E_OUTCAP = -4,   /* output capacity too small */
+    ZGPU_E_UNIT = -5,     /* a unit overflowed its bounded output slot */
+    ZGPU_E_TOOBIG = -6    /* a unit exceeds ZGPU_MAX_UNIT_BYTES */
+};
+
+/* RawDeflate.CompressionType, src/rawdeflate.js:7-12 */
+enum { ZGPU_NONE = 0, ZGPU_FIXED = 1, ZGPU_DYNAMIC = 2 };
+
+/* Batch flags. */
+enum {
+    /* every unit is a complete raw DEFLATE stream, BFINAL on its last block
+     * (one RawDeflate.compress() call per unit, src/rawdeflate.js:102-124) */
+    ZGPU_F_FINAL_EACH = 1u,
+    /* units are consecutive pieces of ONE stream: each ends byte-aligned with
+     * an empty stored block and BFINAL clear, so the host concatenates them;
+     * with ZGPU_F_FINAL_LAST the last unit of the batch carries BFINAL instead
+     * (chunked Gzip/Deflate bodies around src/gzip.js:107-111) */
+    ZGPU_F_SYNC_ALIGN = 2u,
+    ZGPU_F_FINAL_LAST = 4u,
+    /* also compute per-unit CRC-32 / Adler-32 of the unit's INPUT
+     * (CRC32.calc src/crc32.js:14, Adler32.mkHash src/adler32.js:11) */
+    ZGPU_F_WANT_CRC = 16u,
+    ZGPU_F_WANT_ADLER = 32u
+};
+
+#define ZGPU_MAX_UNIT_BYTES (256u << 20)
+
+/* ---- library state ------------------------------------------------------ */
+/* Selects the devices the host-buffer entry points may use (NULL/0 = the
+ * current device).  Optional: every entry point initialises lazily. */
+int zgpu_init(const int *device_ids, int n_devices);
+void zgpu_shutdown(void);
+const char *zgpu_strerror(int code);
+int zgpu_last_hip_error(void);
+/* engine knobs: hash-chain search depth and "good enough" match length */
+int zgpu_set_search(int max_chain, int nice_length);
+
+/* ---- sizing ------------------------------------------------------------- */
+/* Worst-case compressed size of one unit of in_len bytes for any
+ * compressionType (stored-block framing: src/rawdeflate.js:131-153). */
+uint64_t zgpu_deflate_bound(uint64_t in_len);
+
+/* ---- RawDeflate, host buffers -------------------------------------------
+ * Replaces `new RawDeflate(input, {compressionType, lazy}).compress()`
+ * (src/rawdeflate.js:81-124: lz77 :283-361, searchLongestMatch_ :370-395,
+ * getLengths_ :474-493, getCodesFromLengths_ :582-605, fixedHuffman :266-277,
+ * dynamicHuffman :243-259, BitStream src/bitstream.js:42-95) for n_units
+ * independent inputs in one call; it is also what Zip.compress()'s per-file
+ * loop (src/zip.js:119-137) turns into.  in/out are host pointers; the call
+ * copies to the device, runs, copies back and blocks until done.
+ * out_off[i]..out_off[i+1] delimit unit i in out (contiguous).  crc32/adler32
+ * may be NULL. */
+int zgpu_deflate_batch(const uint8_t *in, const uint64_t *in_off, uint32_t n_units,
+                       int ctype, int lazy, uint32_t flags,
+                       uint8_t *out, uint64_t out_cap, uint64_t *out_off,
+                       uint32_t *crc32, uint32_t *adler32);
+
+/* ---- RawDeflate, device-resident plan ------------------------------------
+ * Same operation with inputs and outputs resident in HBM.  A plan holds the
+ * unit table and workspace on the device it was created on and can be run
+ * repeatedly (asynchronously on a HIP stream). */
+typedef struct zgpu_plan zgpu_plan;
+int zgpu_plan_create(zgpu_plan **plan, const uint64_t *in_off, uint32_t n_units,
+                     int ctype, int lazy, uint32_t flags);
+void zgpu_plan_destroy(zgpu_plan *plan);
+/* bytes d_out must hold for zgpu_plan_run (sum of per-unit bounds) */
+uint64_t zgpu_plan_out_bound(const zgpu_plan *plan);
+/* d_in: device pointer to in_off[n_units] input bytes; d_out: device buffer
+ * of out_cap bytes.  stream: hipStream_t (NULL = default stream).  Returns
+ * after enqueueing. */
+int zgpu_plan_run(zgpu_plan *plan, const void *d_in, void *d_out, uint64_t out_cap, void *stream);
+/* Device-side results of the last run (valid once the stream has drained):
+ * out_off: n_units+1 x uint64, crc/adler: n_units x uint32 (zero unless
+ * requested), status: n_units x uint32 (0 = ok). */
+const uint64_t *zgpu_plan_out_off_device(const zgpu_plan *plan);
+const uint32_t *zgpu_plan_crc_device(const zgpu_plan *plan);
+const uint32_t *zgpu_plan_adler_device(const zgpu_plan *plan);
+/* Waits for the stream, copies results to host arrays (any may be NULL) and
+ * returns ZGPU_E_UNIT if any unit reported overflow. */
+int zgpu_plan_fetch(zgpu_plan *plan, uint64_t *out_off, uint32_t *crc32, uint32_t *adler32,
+                    void *stream);
+/* Average device time of the last run's DEFLATE kernel in milliseconds,
+ * measured with HIP events on the run's stream (waits for it). */
+int zgpu_plan_kernel_ms(zgpu_plan *plan, float *deflate_ms, float *total_ms);
+
+/* ---- checksums ----------------------------------------------------------
+ * zgpu_checksum replaces CRC32.calc(data) (src/crc32.js:14-16,25-42) and
+ * Adler32.mkHash(data) (src/adler32.js:11-37) over one host buffer; either
+ * result pointer may be NULL.  The _device form takes a device pointer and
+ * writes the two results to host memory after synchronising the stream. */
+int zgpu_checksum(const uint8_t *in, uint64_t len, uint32_t *crc32, uint32_t *adler32);
+int zgpu_checksum_device(const void *d_in, uint64_t len, uint32_t *crc32, uint32_t *adler32,
+                         void *stream);
+/* Resumable forms: CRC32.update(data, crc) (src/crc32.js:25) and
+ * Adler32.update(adler, data) (src/adler32.js:20). */
+int zgpu_crc32_update(const uint8_t *in, uint64_t len, uint32_t crc, uint32_t *out);
+int zgpu_adler32_update(const uint8_t *in, uint64_t len, uint32_t adler, uint32_t *out);
+/* Device time of the last zgpu_checksum_device kernel on this thread's
+ * device, in milliseconds. */
+int zgpu_checksum_kernel_ms(float *ms);
+/* crc32(A||B) from crc32(A), crc32(B), |B|.  The reference has no combine;
+ * it is pinned by CRC32.update(B, CRC32.calc(A)) (src/crc32.js:25). */
+uint32_t zgpu_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
+/* adler32(A||B) from adler32(A), adler32(B), |B| (pinned by Adler32.update,
+ * src/adler32.js:20). */
+uint32_t zgpu_adler32_combine(uint32_t adler_a, uint32_t adler_b, uint64_t len_b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

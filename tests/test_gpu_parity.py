@@ -1,0 +1,158 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called
+through the C ABI, against the CPU oracle on the same seeded inputs.
+
+Bars: CRC-32 / Adler-32 bit-exact; every stream must decode bit-exactly
+through the strict decoder; compressed size <= 1.03 x the oracle's
+(reference's) size at the same compressionType / lazy.
+"""
+import numpy as np
+import pytest
+
+import _oracle as zo
+
+pytestmark = pytest.mark.gpu
+
+RATIO_BAR = 1.03
+
+
+@pytest.fixture(scope="module")
+def z():
+    import zlib_es_amd
+    return zlib_es_amd
+
+
+def test_checksum_known_answers(z):
+    assert z.checksum(b"123456789")[0] == 0xCBF43926
+    assert z.checksum(b"hoge\n")[0] == 0xB9E2879D
+    assert z.checksum(b"Wikipedia")[1] == 0x11E60398
+    assert z.checksum(b"") == (0, 1)
+
+
+def test_checksum_sizes_and_alignments(z):
+    rng = np.random.default_rng(7)
+    base = rng.integers(0, 256, (3 << 20) + 100, dtype=np.uint8)
+    for n in (1, 2, 3, 4, 15, 16, 17, 63, 64, 65, 255, 4095, 4096, 4097, 65521, 65536, 100_000,
+              (1 << 20) - 1, 1 << 20, (1 << 20) + 1, (3 << 20) + 77):
+        for a in (0, 1, 5, 13):
+            d = base[a:a + n]
+            assert z.checksum(d) == (zo.crc32(d), zo.adler32(d)), (n, a)
+
+
+def test_checksum_golden_cases(z, golden):
+    for c in golden["cases"]:
+        d = zo.gen(c["spec"])
+        assert z.checksum(d) == (c["crc32"], c["adler32"]), c["spec"]
+
+
+def test_checksum_resumable(z):
+    d = zo.gen({"gen": "rnd", "n": 300_000, "seed": 5})
+    for cut in (0, 1, 1024, 65521, 299_999):
+        crc = z.CRC32.update(d[cut:], z.CRC32.calc(d[:cut]))
+        ad = z.Adler32.update(z.Adler32.mkHash(d[:cut]), d[cut:])
+        assert (crc, ad) == (zo.crc32(d), zo.adler32(d))
+    assert z.CRC32.calc(d, 10, 1000) == zo.crc32(d[10:1010])
+
+
+def _roundtrip(z, datas, ctype, lazy=0):
+    outs, crcs, adls = z.deflate_batch(datas, ctype, lazy, want_crc=True, want_adler=True)
+    sizes = []
+    for d, o, c, a in zip(datas, outs, crcs, adls):
+        d = np.asarray(d, dtype=np.uint8)
+        got, used, counts = zo.inflate_raw(o, d.size, want_stats=True)
+        assert got == d.tobytes()
+        assert used == len(o)
+        assert counts[ctype] >= 1 and counts.sum() == counts[ctype]
+        assert c == zo.crc32(d) and a == zo.adler32(d)
+        sizes.append(len(o))
+    return sizes
+
+
+@pytest.mark.parametrize("ctype", [0, 1, 2])
+def test_roundtrip_golden_cases(z, golden, ctype):
+    datas = [zo.gen(c["spec"]) for c in golden["cases"]]
+    sizes = _roundtrip(z, datas, ctype)
+    if ctype == 0:
+        for c, s in zip(golden["cases"], sizes):
+            if c["n"]:
+                assert s == c["raw"]["0"]["len"]  # stored framing is byte-identical in size
+
+
+@pytest.mark.parametrize("ctype", [1, 2])
+def test_ratio_vs_reference(z, golden, ctype):
+    # total over the compressible named cases; the reference sizes are the golden ones
+    tot_gpu = tot_ref = 0
+    datas, refs = [], []
+    for c in golden["cases"]:
+        if c["n"] >= 16384:
+            datas.append(zo.gen(c["spec"]))
+            refs.append(c["raw"][str(ctype)]["len"])
+    sizes = _roundtrip(z, datas, ctype)
+    for c, s, r in zip(datas, sizes, refs):
+        tot_gpu += s
+        tot_ref += r
+    assert tot_gpu <= RATIO_BAR * tot_ref, (tot_gpu, tot_ref)
+
+
+def test_roundtrip_edge_sizes(z):
+    rng = np.random.default_rng(11)
+    datas = []
+    for n in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 255, 256, 257, 258, 259, 260, 1023, 1024, 1025, 2047, 2048, 2049,
+              4096, 65535, 65536, 65537, 70000, 131072, 200_001):
+        datas.append(zo.gen({"gen": "text", "n": n, "seed": n + 1}))
+        datas.append(rng.integers(0, 256, n, dtype=np.uint8))
+        datas.append(np.zeros(n, dtype=np.uint8))
+        datas.append(zo.gen({"gen": "small-alpha", "n": n, "seed": n + 3, "k": 2}))
+    for ct in (1, 2):
+        _roundtrip(z, datas, ct)
+
+
+def test_roundtrip_fuzz_units(z, golden):
+    datas = [zo.gen(r["spec"]) for r in golden["fuzz"]]
+    for ct in (1, 2):
+        sizes = _roundtrip(z, datas, ct)
+        ref = sum(r["l%d" % ct] for r in golden["fuzz"])
+        assert sum(sizes) <= 1.05 * ref  # tiny units: per-unit header noise dominates
+
+
+def test_lazy_roundtrip_and_gain(z):
+    datas = [zo.gen({"gen": "text", "n": 65536, "seed": s}) for s in range(8)]
+    s0 = sum(_roundtrip(z, datas, 2, 0))
+    s8 = sum(_roundtrip(z, datas, 2, 8))
+    s32 = sum(_roundtrip(z, datas, 2, 32))
+    assert s8 <= s0 and s32 <= s8 * 1.001
+
+
+def test_unaligned_units_in_one_batch(z):
+    # zip-like packing: units start at arbitrary byte offsets inside one buffer
+    rng = np.random.default_rng(2)
+    datas = [zo.gen({"gen": "text", "n": int(n), "seed": i}) for i, n in enumerate(rng.integers(1, 16384, 64))]
+    _roundtrip(z, datas, 2)
+    _roundtrip(z, datas, 1)
+
+
+def test_large_unit_sliding_window(z):
+    # a unit longer than the 64 KiB LDS ring exercises ring refill and wrap
+    d = zo.gen({"gen": "text", "n": 1 << 20, "seed": 42})
+    (s,) = _roundtrip(z, [d], 2)
+    ref = len(zo.rawdeflate(d, 2, heap32=True))
+    assert s <= RATIO_BAR * ref
+    d2 = zo.gen({"gen": "rndseq", "n": 300_000, "seed": 9})
+    _roundtrip(z, [d2, d], 1)
+
+
+def test_sync_align_concatenates(z):
+    # chunks of one stream: each ends byte-aligned with an empty stored block; last carries BFINAL
+    d = zo.gen({"gen": "text", "n": 300_000, "seed": 4})
+    chunks = [d[i:i + 65536] for i in range(0, d.size, 65536)]
+    N = z._native
+    outs, _, _ = z.deflate_batch(chunks, 2, 0, flags=N.F_SYNC_ALIGN | N.F_FINAL_LAST)
+    stream = b"".join(outs)
+    got, used = zo.inflate_raw(stream, d.size, want_used=True)
+    assert got == d.tobytes() and used == len(stream)
+    for o in outs[:-1]:
+        assert o[-4:] == b"\x00\x00\xff\xff"
+
+
+def test_invalid_arguments(z):
+    with pytest.raises(z.ZgpuError):
+        z.deflate_batch([b"abc"], 3)

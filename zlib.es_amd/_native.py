@@ -1,0 +1,225 @@
+"""ctypes binding of libzgpu.so (the C ABI in include/zgpu.h).
+
+The library is the only compute path: if it is missing or no GPU is usable the
+calls raise, they never fall back to a CPU implementation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzgpu.so")
+
+NONE, FIXED, DYNAMIC = 0, 1, 2
+F_FINAL_EACH, F_SYNC_ALIGN, F_FINAL_LAST, F_WANT_CRC, F_WANT_ADLER = 1, 2, 4, 16, 32
+
+# every symbol include/zgpu.h declares
+SYMBOLS = [
+    "zgpu_init", "zgpu_shutdown", "zgpu_strerror", "zgpu_last_hip_error", "zgpu_set_search",
+    "zgpu_deflate_bound", "zgpu_deflate_batch", "zgpu_plan_create", "zgpu_plan_destroy",
+    "zgpu_plan_out_bound", "zgpu_plan_run", "zgpu_plan_out_off_device", "zgpu_plan_crc_device",
+    "zgpu_plan_adler_device", "zgpu_plan_fetch", "zgpu_plan_kernel_ms", "zgpu_checksum",
+    "zgpu_checksum_device", "zgpu_crc32_update", "zgpu_adler32_update", "zgpu_checksum_kernel_ms",
+    "zgpu_crc32_combine", "zgpu_adler32_combine",
+]
+
+_lib = None
+
+
+class ZgpuError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        msg = lib().zgpu_strerror(code).decode() if _lib is not None else "libzgpu error"
+        hip = lib().zgpu_last_hip_error() if _lib is not None else 0
+        super().__init__("%s: %s (code %d, hip %d)" % (what or "zgpu", msg, code, hip))
+
+
+def lib():
+    """Load libzgpu.so (built in-tree by zlib.es_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libzgpu.so not built: run `make -C zlib.es_amd/csrc` "
+                          "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    L.zgpu_init.restype = i32
+    L.zgpu_init.argtypes = [C.POINTER(i32), i32]
+    L.zgpu_shutdown.restype = None
+    L.zgpu_strerror.restype = C.c_char_p
+    L.zgpu_strerror.argtypes = [i32]
+    L.zgpu_last_hip_error.restype = i32
+    L.zgpu_set_search.restype = i32
+    L.zgpu_set_search.argtypes = [i32, i32]
+    L.zgpu_deflate_bound.restype = u64
+    L.zgpu_deflate_bound.argtypes = [u64]
+    L.zgpu_deflate_batch.restype = i32
+    L.zgpu_deflate_batch.argtypes = [vp, vp, u32, i32, i32, u32, vp, u64, vp, vp, vp]
+    L.zgpu_plan_create.restype = i32
+    L.zgpu_plan_create.argtypes = [C.POINTER(vp), vp, u32, i32, i32, u32]
+    L.zgpu_plan_destroy.restype = None
+    L.zgpu_plan_destroy.argtypes = [vp]
+    L.zgpu_plan_out_bound.restype = u64
+    L.zgpu_plan_out_bound.argtypes = [vp]
+    L.zgpu_plan_run.restype = i32
+    L.zgpu_plan_run.argtypes = [vp, vp, vp, u64, vp]
+    for n in ("zgpu_plan_out_off_device", "zgpu_plan_crc_device", "zgpu_plan_adler_device"):
+        getattr(L, n).restype = vp
+        getattr(L, n).argtypes = [vp]
+    L.zgpu_plan_fetch.restype = i32
+    L.zgpu_plan_fetch.argtypes = [vp, vp, vp, vp, vp]
+    L.zgpu_plan_kernel_ms.restype = i32
+    L.zgpu_plan_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.zgpu_checksum.restype = i32
+    L.zgpu_checksum.argtypes = [vp, u64, C.POINTER(u32), C.POINTER(u32)]
+    L.zgpu_checksum_device.restype = i32
+    L.zgpu_checksum_device.argtypes = [vp, u64, C.POINTER(u32), C.POINTER(u32), vp]
+    L.zgpu_crc32_update.restype = i32
+    L.zgpu_crc32_update.argtypes = [vp, u64, u32, C.POINTER(u32)]
+    L.zgpu_adler32_update.restype = i32
+    L.zgpu_adler32_update.argtypes = [vp, u64, u32, C.POINTER(u32)]
+    L.zgpu_checksum_kernel_ms.restype = i32
+    L.zgpu_checksum_kernel_ms.argtypes = [C.POINTER(C.c_float)]
+    L.zgpu_crc32_combine.restype = u32
+    L.zgpu_crc32_combine.argtypes = [u32, u32, u64]
+    L.zgpu_adler32_combine.restype = u32
+    L.zgpu_adler32_combine.argtypes = [u32, u32, u64]
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise ZgpuError(rc, what)
+
+
+def _u8(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+def deflate_bound(n):
+    return int(lib().zgpu_deflate_bound(n))
+
+
+def set_search(max_chain, nice_length=258):
+    _check(lib().zgpu_set_search(max_chain, nice_length), "zgpu_set_search")
+
+
+def crc32_combine(a, b, len_b):
+    return int(lib().zgpu_crc32_combine(a, b, len_b))
+
+
+def adler32_combine(a, b, len_b):
+    return int(lib().zgpu_adler32_combine(a, b, len_b))
+
+
+def checksum(data):
+    """(crc32, adler32) of a host buffer, computed on the GPU."""
+    a = _u8(data)
+    c, ad = C.c_uint32(0), C.c_uint32(0)
+    _check(lib().zgpu_checksum(a.ctypes.data if a.size else None, a.size, C.byref(c), C.byref(ad)),
+           "zgpu_checksum")
+    return c.value, ad.value
+
+
+def crc32_update(data, crc):
+    a = _u8(data)
+    out = C.c_uint32(0)
+    _check(lib().zgpu_crc32_update(a.ctypes.data if a.size else None, a.size, crc, C.byref(out)),
+           "zgpu_crc32_update")
+    return out.value
+
+
+def adler32_update(data, adler):
+    a = _u8(data)
+    out = C.c_uint32(0)
+    _check(lib().zgpu_adler32_update(a.ctypes.data if a.size else None, a.size, adler, C.byref(out)),
+           "zgpu_adler32_update")
+    return out.value
+
+
+def checksum_device(ptr, nbytes, stream=None):
+    c, ad = C.c_uint32(0), C.c_uint32(0)
+    _check(lib().zgpu_checksum_device(ptr, nbytes, C.byref(c), C.byref(ad), stream), "zgpu_checksum_device")
+    return c.value, ad.value
+
+
+def checksum_kernel_ms():
+    ms = C.c_float(0)
+    _check(lib().zgpu_checksum_kernel_ms(C.byref(ms)), "zgpu_checksum_kernel_ms")
+    return ms.value
+
+
+def deflate_batch(units, ctype=DYNAMIC, lazy=0, flags=F_FINAL_EACH, want_crc=False, want_adler=False):
+    """Compress a list of byte buffers in one GPU call (host buffers).
+
+    Returns (list of compressed bytes, crc32 list or None, adler32 list or None).
+    """
+    arrs = [_u8(u) for u in units]
+    n = len(arrs)
+    if n == 0:
+        return [], ([] if want_crc else None), ([] if want_adler else None)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([a.size for a in arrs], dtype=np.uint64)
+    total = int(off[-1])
+    flat = np.concatenate(arrs) if total else np.zeros(1, dtype=np.uint8)
+    cap = sum(deflate_bound(a.size) + 48 for a in arrs) + 64
+    out = np.empty(cap, dtype=np.uint8)
+    out_off = np.zeros(n + 1, dtype=np.uint64)
+    crc = np.zeros(n, dtype=np.uint32) if want_crc else None
+    adl = np.zeros(n, dtype=np.uint32) if want_adler else None
+    rc = lib().zgpu_deflate_batch(
+        flat.ctypes.data, off.ctypes.data, n, ctype, lazy, flags, out.ctypes.data, cap,
+        out_off.ctypes.data, crc.ctypes.data if want_crc else None, adl.ctypes.data if want_adler else None)
+    _check(rc, "zgpu_deflate_batch")
+    res = [out[int(out_off[i]):int(out_off[i + 1])].tobytes() for i in range(n)]
+    return res, (crc.tolist() if want_crc else None), (adl.tolist() if want_adler else None)
+
+
+class Plan:
+    """Device-resident batch: unit table + workspace on the current HIP device."""
+
+    def __init__(self, in_off, ctype=DYNAMIC, lazy=0, flags=F_FINAL_EACH):
+        self.in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+        self.n_units = self.in_off.size - 1
+        self._h = C.c_void_p(None)
+        _check(lib().zgpu_plan_create(C.byref(self._h), self.in_off.ctypes.data, self.n_units, ctype, lazy,
+                                      flags), "zgpu_plan_create")
+
+    @property
+    def out_bound(self):
+        return int(lib().zgpu_plan_out_bound(self._h))
+
+    def run(self, d_in, d_out, out_cap, stream=None):
+        _check(lib().zgpu_plan_run(self._h, d_in, d_out, out_cap, stream), "zgpu_plan_run")
+
+    def fetch(self, want_crc=False, want_adler=False, stream=None):
+        off = np.zeros(self.n_units + 1, dtype=np.uint64)
+        crc = np.zeros(self.n_units, dtype=np.uint32) if want_crc else None
+        adl = np.zeros(self.n_units, dtype=np.uint32) if want_adler else None
+        _check(lib().zgpu_plan_fetch(self._h, off.ctypes.data, crc.ctypes.data if want_crc else None,
+                                     adl.ctypes.data if want_adler else None, stream), "zgpu_plan_fetch")
+        return off, crc, adl
+
+    def kernel_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        _check(lib().zgpu_plan_kernel_ms(self._h, C.byref(a), C.byref(b)), "zgpu_plan_kernel_ms")
+        return a.value, b.value
+
+    def out_off_device(self):
+        return lib().zgpu_plan_out_off_device(self._h)
+
+    def close(self):
+        if self._h:
+            lib().zgpu_plan_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

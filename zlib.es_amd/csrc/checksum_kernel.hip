@@ -1,0 +1,177 @@
+// CRC-32 + Adler-32 in one pass over HBM (gfx950).
+//
+// Replaces CRC32.calc/update (src/crc32.js:14-42: byte-at-a-time table CRC,
+// reflected polynomial 0xEDB88320, init/final xor 0xFFFFFFFF) and
+// Adler32.mkHash/update (src/adler32.js:11-37) with bit-identical results.
+//
+// One persistent 256-thread workgroup folds one segment [off[i], off[i+1]) at
+// a time.  Lanes read adjacent 16-byte pieces (fully coalesced); lane t owns
+// pieces t, t+256, t+512, ... and keeps the CRC remainder of its pieces as
+//     A <- A * x^(8*4096)  xor  crc16(piece)
+// (4 lookups in the "advance 4096 bytes" tables + 16 lookups in the slice
+// tables, all in LDS).  CRC is linear, so the 256 partial remainders are then
+// folded pairwise with multiplications by x^(128*d) in GF(2)[x]/P.  The
+// 0xFFFFFFFF preset is folded into the first four data bytes; leading bytes
+// of the first (address-aligned) piece that lie before the segment are zeroed,
+// which leaves a zero CRC state unchanged.  Adler-32 uses per-lane sums
+// sum(b) and sum(q*b) (v_dot4_u32_u8) and s2 = n + n*sum(b) - sum(q*b).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "zgpu_dev.h"
+
+namespace {
+constexpr int T = ZGPU_CK_THREADS;
+constexpr uint32_t POLY = 0xEDB88320u;
+constexpr uint32_t ADLER_MOD = 65521u;
+
+// (a * b) mod P in the reflected representation (bit 31 = x^0)
+__device__ inline uint32_t gf_mul(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) {
+        p ^= (a & 0x80000000u) ? b : 0u;
+        a <<= 1;
+        b = (b >> 1) ^ ((b & 1u) ? POLY : 0u);
+    }
+    return p;
+}
+
+__device__ inline uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot4(a, b, c, false);
+}
+}  // namespace
+
+// tables: [0..16*256) slice tables Tk[b] = crc state of byte b followed by k
+// zero bytes; [16*256..20*256) advance tables Sj[v] = (v << 8j) advanced by
+// 16*T bytes; [20*256..20*256+8) x^(128*d) for d = 1,2,4,..,128.
+extern "C" __global__ void __launch_bounds__(ZGPU_CK_THREADS)
+zgpu_checksum_kernel(const uint8_t *in, const uint64_t *seg_off, uint32_t n_segs,
+                     const uint32_t *tables, uint32_t *out_crc, uint32_t *out_adler) {
+    __shared__ uint32_t tab[20 * 256];
+    __shared__ uint32_t xpow[8];
+    __shared__ uint32_t red_crc[T / 64];
+    __shared__ unsigned long long red_sb[T / 64], red_sw[T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 20 * 256; i += T) tab[i] = tables[i];
+    if (tid < 8) xpow[tid] = tables[20 * 256 + tid];
+    __syncthreads();
+    const uint32_t *S = tab + 16 * 256;
+
+    for (uint32_t sg = blockIdx.x; sg < n_segs; sg += gridDim.x) {
+        const uint64_t o = seg_off[sg], n = seg_off[sg + 1] - o;
+        const uint8_t *p0 = in + o;
+        uint32_t crc_state;
+        unsigned long long sb = 0, sw = 0;  // sum b, sum q*b
+        uint64_t tail_lo, tail_hi;          // byte range finished serially by thread 0
+        uint32_t B = 0;
+        if (n < 64) {
+            tail_lo = 0;
+            tail_hi = n;
+            crc_state = 0xffffffffu;
+        } else {
+            const uint32_t a = (uint32_t)((uintptr_t)p0 & 15u);
+            const uint8_t *vstart = p0 - a;
+            const uint64_t kv = (a + n) >> 4;  // full 16-byte pieces (first may start before p0)
+            const uint32_t pad = (uint32_t)((T - (kv % T)) % T);
+            const uint64_t rounds = (kv + pad) / T;
+            uint32_t A = 0;
+            for (uint64_t r = 0; r < rounds; ++r) {
+                const int64_t i = (int64_t)(r * T + tid) - (int64_t)pad;
+                // advance by 16*T bytes
+                A = S[A & 0xff] ^ S[256 + ((A >> 8) & 0xff)] ^ S[512 + ((A >> 16) & 0xff)] ^
+                    S[768 + (A >> 24)];
+                if (i >= 0) {
+                    uint4 v = *(const uint4 *)(vstart + 16 * (uint64_t)i);
+                    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                    const int64_t q0 = 16 * i - (int64_t)a;  // segment index of byte 0
+                    if (i < 2) {
+                        // zero bytes before the segment; fold the preset into bytes 0..3
+                        uint32_t xr[4] = {0, 0, 0, 0};
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            const int64_t q = q0 + k;
+                            if (q < 0) w[k >> 2] &= ~(0xffu << (8 * (k & 3)));
+                            if (q >= 0 && q < 4) xr[k >> 2] |= 0xffu << (8 * (k & 3));
+                        }
+                        // Adler sees the unmodified bytes
+                        const uint32_t s = dot4(w[0], 0x01010101u, dot4(w[1], 0x01010101u,
+                                           dot4(w[2], 0x01010101u, dot4(w[3], 0x01010101u, 0))));
+                        const uint32_t j = dot4(w[0], 0x03020100u, dot4(w[1], 0x07060504u,
+                                           dot4(w[2], 0x0b0a0908u, dot4(w[3], 0x0f0e0d0cu, 0))));
+                        sb += s;
+                        sw += (unsigned long long)((long long)q0 * (long long)s + (long long)j);
+                        w[0] ^= xr[0];
+                        w[1] ^= xr[1];
+                        w[2] ^= xr[2];
+                        w[3] ^= xr[3];
+                    } else {
+                        const uint32_t s = dot4(w[0], 0x01010101u, dot4(w[1], 0x01010101u,
+                                           dot4(w[2], 0x01010101u, dot4(w[3], 0x01010101u, 0))));
+                        const uint32_t j = dot4(w[0], 0x03020100u, dot4(w[1], 0x07060504u,
+                                           dot4(w[2], 0x0b0a0908u, dot4(w[3], 0x0f0e0d0cu, 0))));
+                        sb += s;
+                        sw += (unsigned long long)q0 * s + j;
+                    }
+                    uint32_t c = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t x = w[k];
+                        c ^= tab[(15 - 4 * k) * 256 + (x & 0xff)] ^
+                             tab[(14 - 4 * k) * 256 + ((x >> 8) & 0xff)] ^
+                             tab[(13 - 4 * k) * 256 + ((x >> 16) & 0xff)] ^
+                             tab[(12 - 4 * k) * 256 + (x >> 24)];
+                    }
+                    A ^= c;
+                }
+            }
+            // fold the 256 lane remainders: lane t must be advanced by 16*(T-1-t) bytes
+#pragma unroll
+            for (int d = 1, lv = 0; d < 64; d <<= 1, ++lv) {
+                const uint32_t other = __shfl_down(A, d, 64);
+                if ((lane & (2 * d - 1)) == 0) A = gf_mul(A, xpow[lv]) ^ other;
+            }
+            if (lane == 0) red_crc[wave] = A;
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t x = red_crc[0];
+                x = gf_mul(x, xpow[6]) ^ red_crc[1];
+                uint32_t y = red_crc[2];
+                y = gf_mul(y, xpow[6]) ^ red_crc[3];
+                B = gf_mul(x, xpow[7]) ^ y;
+            }
+            crc_state = B;
+            tail_lo = kv * 16 - a;
+            tail_hi = n;
+        }
+        // Adler partial sums across the workgroup
+        for (int d = 32; d > 0; d >>= 1) {
+            sb += __shfl_down(sb, d, 64);
+            sw += __shfl_down(sw, d, 64);
+        }
+        if (lane == 0) {
+            red_sb[wave] = sb;
+            red_sw[wave] = sw;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long tsb = 0, tsw = 0;
+            for (int w = 0; w < T / 64; ++w) {
+                tsb += red_sb[w];
+                tsw += red_sw[w];
+            }
+            uint32_t c = crc_state;
+            for (uint64_t q = tail_lo; q < tail_hi; ++q) {
+                const uint32_t b = p0[q];
+                c = (c >> 8) ^ tab[(c ^ b) & 0xff];
+                tsb += b;
+                tsw += q * b;
+            }
+            out_crc[sg] = c ^ 0xffffffffu;
+            const unsigned long long nm = n % ADLER_MOD, bm = tsb % ADLER_MOD, wm = tsw % ADLER_MOD;
+            const uint32_t s1 = (uint32_t)((1 + bm) % ADLER_MOD);
+            const uint32_t s2 = (uint32_t)((nm + nm * bm + (ADLER_MOD - wm)) % ADLER_MOD);
+            out_adler[sg] = (s2 << 16) | s1;
+        }
+        __syncthreads();
+    }
+}

@@ -1,0 +1,890 @@
+// DEFLATE encoder kernel for gfx950 (MI355X): one 1024-thread workgroup per
+// unit (block / zip entry / stream chunk), persistent over a unit queue.
+//
+// Replaces, per unit, the reference's RawDeflate.compress() pipeline
+// (src/rawdeflate.js:102-124): lz77 + searchLongestMatch_ (:283-395), the
+// Huffman code construction (:474-605), the block header (:176-236) and the
+// bit emission (:243-277, src/bitstream.js:42-95).
+//
+// Per unit the workgroup streams through the input in 1 KiB chunks:
+//   load    input -> 64 KiB LDS ring (the 32 KiB window stays resident)
+//   insert  hash every position, sort (hash,pos) pairs, link hash chains
+//   search  one lane per position walks its chain (bounded depth), scoring
+//           candidates with 4-byte xor/ctz compares against the LDS ring
+//   parse   greedy / one-step-lazy successor per position, reachable set by
+//           pointer doubling, tokens compacted with a workgroup prefix sum,
+//           symbol histograms by LDS atomics
+// and every 64 chunks (or at the end) closes a DEFLATE block:
+//   codes   length-limited Huffman code lengths + canonical codes
+//   emit    per-token bit strings, prefix sum of bit lengths, LDS-staged
+//           OR-merge, coalesced dword stores
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "zgpu_dev.h"
+
+namespace {
+
+constexpr int WG = 1024;
+constexpr int CHUNK = 1024;         // positions inserted/searched per step
+constexpr int HBITS = 13;           // hash-head table entries = 1 << HBITS
+constexpr uint32_t RING = 65536;    // LDS input ring (bytes)
+constexpr uint32_t RING_PAD = 272;  // mirror of ring[0..272) after the end
+constexpr uint32_t WMASK = 0x7fff;  // chain slots (32 Ki positions)
+constexpr uint32_t MAXDIST = 32768 - CHUNK;
+constexpr int BLK_CHUNKS = 64;      // one DEFLATE block per 64 KiB of input
+constexpr uint32_t REFILL = 16384;  // ring refill granule
+constexpr int STAGE_WORDS = 1792;   // bit staging (>= header + 1024*48/32 + carry)
+
+// ---- LDS map (bytes) -------------------------------------------------------
+constexpr uint32_t L_RING = 0;
+constexpr uint32_t L_PREV = L_RING + RING + RING_PAD;      // u16[32768]
+constexpr uint32_t L_HEAD = L_PREV + 65536;                // u16[1<<HBITS]
+constexpr uint32_t L_FL = L_HEAD + (2u << HBITS);          // u32[288] lit/len freqs
+constexpr uint32_t L_FD = L_FL + 288 * 4;                  // u32[32]  dist freqs
+constexpr uint32_t L_MISC = L_FD + 32 * 4;                 // u32[64]  scan partials, control
+constexpr uint32_t L_SCR = L_MISC + 64 * 4;                // phase scratch
+constexpr uint32_t SCR_BYTES = 14336;
+constexpr uint32_t L_TOTAL = L_SCR + SCR_BYTES;
+static_assert(L_TOTAL <= 163840, "LDS budget");
+
+// scratch, insert phase
+constexpr uint32_t S_SORT = 0;  // u32[1024]
+// scratch, search/parse phase
+constexpr uint32_t S_MARR = 0;                       // u32[CHUNK+2] match per position
+constexpr uint32_t S_JA = S_MARR + (CHUNK + 2) * 4;  // u16[CHUNK+2]
+constexpr uint32_t S_JB = S_JA + (CHUNK + 2) * 2;    // u16[CHUNK+2]
+constexpr uint32_t S_MARK = S_JB + (CHUNK + 2) * 2;  // u8[CHUNK+4]
+static_assert(S_MARK + CHUNK + 4 <= SCR_BYTES, "parse scratch");
+// scratch, block close phase
+constexpr uint32_t S_STAGE = 0;                        // u32[STAGE_WORDS]
+constexpr uint32_t S_LLTAB = S_STAGE + STAGE_WORDS * 4;  // u32[288] code | len<<16
+constexpr uint32_t S_DTAB = S_LLTAB + 288 * 4;           // u32[32]
+constexpr uint32_t S_HUF = S_DTAB + 32 * 4;              // Huffman build scratch
+constexpr uint32_t HUF_BYTES = SCR_BYTES - S_HUF;
+// Huffman build scratch map (bytes from S_HUF)
+constexpr uint32_t H_KEY = 0;        // u32[512] sort keys
+constexpr uint32_t H_PARENT = 2048;  // u16[640]
+constexpr uint32_t H_IW = 3328;      // u32[288] internal weights / depths / first codes
+constexpr uint32_t H_LENS = 4480;    // u8[288]
+constexpr uint32_t H_CLF = 4768;     // u32[20] code-length symbol freqs
+constexpr uint32_t H_CLTAB = 4848;   // u32[20]
+constexpr uint32_t H_RLE = 4928;     // u16[320]
+constexpr uint32_t H_NRLE = 5568;    // u32
+static_assert(HUF_BYTES >= 5572, "huffman scratch");
+
+// misc words
+enum { M_SCAN = 0 /*[32]*/, M_UNIT = 32, M_NEXTPOS = 33, M_NTOK = 34, M_TMP = 35, M_OVF = 36, M_CARRY = 37 };
+
+struct Lds {
+    uint8_t *base;
+    __device__ uint8_t *ring() const { return base + L_RING; }
+    __device__ uint16_t *prev() const { return (uint16_t *)(base + L_PREV); }
+    __device__ uint16_t *head() const { return (uint16_t *)(base + L_HEAD); }
+    __device__ uint32_t *fl() const { return (uint32_t *)(base + L_FL); }
+    __device__ uint32_t *fd() const { return (uint32_t *)(base + L_FD); }
+    __device__ uint32_t *misc() const { return (uint32_t *)(base + L_MISC); }
+    __device__ uint8_t *scr() const { return base + L_SCR; }
+};
+
+__device__ inline uint32_t ld4u(const uint8_t *ring, uint32_t idx) {
+    const uint32_t *w = (const uint32_t *)(ring + (idx & ~3u));
+    uint32_t lo = w[0], hi = w[1];
+    return __builtin_amdgcn_alignbyte(hi, lo, idx & 3u);
+}
+
+__device__ inline uint32_t hash3(uint32_t w) {
+    return ((w & 0xffffffu) * 0x9E3779B1u) >> (32 - HBITS);
+}
+
+// exclusive prefix sum over the workgroup; returns this thread's offset and
+// the total through *total.  Uses misc[M_SCAN..+16].  Two barriers.
+__device__ inline uint32_t block_scan_excl(uint32_t v, uint32_t *total, uint32_t *part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) part[wave] = x;
+    __syncthreads();
+    uint32_t wsum = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < WG / 64; ++w) {
+        uint32_t p = part[w];
+        if (w < wave) wsum += p;
+        tot += p;
+    }
+    __syncthreads();
+    *total = tot;
+    return wsum + x - v;
+}
+
+// bitonic sort of n (power of two, <= 1024) u32 keys in LDS, ascending.
+__device__ inline void bitonic_sort(uint32_t *a, int n) {
+    const int t = threadIdx.x;
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (t < n) {
+                int ixj = t ^ j;
+                if (ixj > t) {
+                    uint32_t x = a[t], y = a[ixj];
+                    bool up = (t & k) == 0;
+                    if ((x > y) == up) {
+                        a[t] = y;
+                        a[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// RFC 1951 length symbol for l = len-3 (0..255): symbol, extra bit count, extra value
+__device__ inline void len_sym(uint32_t l, uint32_t &sym, uint32_t &eb, uint32_t &ev) {
+    if (l < 8) {
+        sym = 257 + l;
+        eb = 0;
+        ev = 0;
+    } else if (l == 255) {
+        sym = 285;
+        eb = 0;
+        ev = 0;
+    } else {
+        uint32_t n = 31 - __builtin_clz(l);
+        sym = 257 + 4 * (n - 1) + ((l >> (n - 2)) & 3);
+        eb = n - 2;
+        ev = l & ((1u << eb) - 1);
+    }
+}
+// distance symbol for dm = dist-1 (0..32767)
+__device__ inline void dist_sym(uint32_t dm, uint32_t &sym, uint32_t &eb, uint32_t &ev) {
+    if (dm < 4) {
+        sym = dm;
+        eb = 0;
+        ev = 0;
+    } else {
+        uint32_t n = 31 - __builtin_clz(dm);
+        sym = 2 * n + ((dm >> (n - 1)) & 1);
+        eb = n - 1;
+        ev = dm & ((1u << eb) - 1);
+    }
+}
+
+// ---- serial bit writer into the staging words (thread 0 only) --------------
+struct BitW {
+    uint32_t *stage;
+    uint32_t rel;  // bit position relative to stage[0]
+    __device__ void put(uint32_t v, uint32_t nb) {
+        if (!nb) return;
+        uint32_t w = rel >> 5, sh = rel & 31;
+        uint64_t x = (uint64_t)v << sh;
+        stage[w] |= (uint32_t)x;
+        if (sh + nb > 32) stage[w + 1] |= (uint32_t)(x >> 32);
+        rel += nb;
+    }
+};
+
+// ---- Huffman code lengths (length-limited), canonical codes ----------------
+// freq[0..nsym) -> len[0..nsym), bit-reversed codes packed as code | len<<16 in
+// tab[].  The workgroup sorts; thread 0 runs the two-queue tree build and the
+// overflow repair.  At least two symbols get a code so every code set is
+// complete.  scratch: >= 4096 bytes.
+__device__ void build_codes(uint32_t *freq, int nsym, int maxbits, uint32_t *tab, uint8_t *scratch) {
+    const int t = threadIdx.x;
+    uint32_t *key = (uint32_t *)(scratch + H_KEY);
+    uint16_t *parent = (uint16_t *)(scratch + H_PARENT);
+    uint32_t *iw = (uint32_t *)(scratch + H_IW);
+    uint8_t *lens = scratch + H_LENS;  // code length per symbol
+    if (t == 0) {
+        int nz = 0;
+        for (int i = 0; i < nsym && nz < 2; ++i) nz += freq[i] != 0;
+        // force two coded symbols (keeps the code complete)
+        for (int i = 0; nz < 2 && i < nsym; ++i)
+            if (freq[i] == 0) {
+                freq[i] = 1;
+                ++nz;
+            }
+    }
+    __syncthreads();
+    if (t < 512) key[t] = (t < nsym && freq[t]) ? ((freq[t] << 9) | (uint32_t)t) : 0xffffffffu;
+    __syncthreads();
+    bitonic_sort(key, 512);
+    if (t < 288) lens[t] = 0;
+    __syncthreads();
+    if (t == 0) {
+        int m = 0;
+        while (m < nsym && key[m] != 0xffffffffu) ++m;
+        // two-queue merge: leaves 0..m-1 (ascending weight), internal m..2m-2
+        int li = 0, ii = 0;
+        for (int k = 0; k < m - 1; ++k) {
+            uint32_t w = 0;
+            for (int r = 0; r < 2; ++r) {
+                bool take_leaf;
+                if (li >= m)
+                    take_leaf = false;
+                else if (ii >= k)
+                    take_leaf = true;
+                else
+                    take_leaf = (key[li] >> 9) <= iw[ii];
+                if (take_leaf) {
+                    w += key[li] >> 9;
+                    parent[li++] = (uint16_t)(m + k);
+                } else {
+                    w += iw[ii];
+                    parent[m + ii++] = (uint16_t)(m + k);
+                }
+            }
+            iw[k] = w;
+        }
+        // depths top-down (reuse iw as depth of internal nodes)
+        uint32_t blc[32];
+        for (int b = 0; b < 32; ++b) blc[b] = 0;
+        iw[m - 2] = 0;
+        for (int k = m - 3; k >= 0; --k) iw[k] = iw[parent[m + k] - m] + 1;
+        int overflow = 0;
+        for (int i = 0; i < m; ++i) {
+            int d = (int)iw[parent[i] - m] + 1;
+            if (d > maxbits) {
+                d = maxbits;
+                ++overflow;
+            }
+            blc[d]++;
+        }
+        // Kraft repair: move the deepest leaves up until the code fits
+        while (overflow > 0) {
+            int bits = maxbits - 1;
+            while (blc[bits] == 0) --bits;
+            blc[bits]--;
+            blc[bits + 1] += 2;
+            blc[maxbits]--;
+            overflow -= 2;
+        }
+        // assign lengths in sorted order: rarest symbols get the longest codes
+        int r = 0;
+        for (int b = maxbits; b >= 1; --b)
+            for (uint32_t c = 0; c < blc[b]; ++c) lens[key[r++] & 511] = (uint8_t)b;
+        // canonical first codes per length
+        uint32_t code = 0;
+        uint32_t *next = iw;  // reuse [0..16)
+        for (int b = 1; b <= maxbits; ++b) {
+            code = (code + blc[b - 1]) << 1;
+            next[b] = code;
+        }
+    }
+    __syncthreads();
+    // canonical code of symbol t = first[len] + #{s < t : len[s] == len[t]}
+    if (t < nsym) {
+        uint32_t l = lens[t], v = 0;
+        if (l) {
+            uint32_t rank = 0;
+            for (int s = 0; s < t; ++s) rank += lens[s] == l;
+            uint32_t c = iw[l] + rank;
+            v = (__brev(c) >> (32 - l)) | (l << 16);
+        }
+        tab[t] = v;
+    }
+    __syncthreads();
+}
+
+struct Params {
+    const uint8_t *in;
+    const uint64_t *in_off;    // n_units+1
+    const uint64_t *slot_off;  // n_units+1, 16-byte aligned slots in out_tmp
+    uint8_t *out_tmp;
+    uint32_t *out_size;  // n_units
+    uint32_t *status;    // n_units
+    uint32_t *tok;       // gridDim.x * TOK_CAP
+    uint32_t *counter;   // unit queue head
+    uint32_t n_units;
+    int ctype, lazy, max_chain, nice;
+    uint32_t flags;
+};
+
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(WG)
+zgpu_deflate_kernel(Params P) {
+    __shared__ __align__(16) uint8_t lds_raw[L_TOTAL];
+    Lds L{lds_raw};
+    const int tid = threadIdx.x;
+    uint8_t *ring = L.ring();
+    uint16_t *prevt = L.prev();
+    uint16_t *head = L.head();
+    uint32_t *fl = L.fl(), *fd = L.fd(), *misc = L.misc();
+    uint8_t *scr = L.scr();
+    uint32_t *tokbuf = P.tok + (size_t)blockIdx.x * ZGPU_TOK_CAP;
+
+    for (;;) {
+        if (tid == 0) misc[M_UNIT] = atomicAdd(P.counter, 1u);
+        __syncthreads();
+        const uint32_t u = misc[M_UNIT];
+        __syncthreads();
+        if (u >= P.n_units) break;
+
+        const uint8_t *in = P.in + P.in_off[u];
+        const uint32_t n = (uint32_t)(P.in_off[u + 1] - P.in_off[u]);
+        uint32_t *out32 = (uint32_t *)(P.out_tmp + P.slot_off[u]);
+        const uint32_t cap_words = (uint32_t)((P.slot_off[u + 1] - P.slot_off[u]) >> 2);
+        const bool final_unit =
+            (P.flags & 1u) || ((P.flags & 4u) && u == P.n_units - 1) || !(P.flags & 2u);
+        const bool sync_unit = !final_unit;
+
+        // ---- unit init ----
+        for (int i = tid; i < (1 << HBITS) / 8; i += WG)
+            ((uint4 *)head)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        for (int i = tid; i < 320; i += WG) fl[i] = 0;  // fl[288] + fd[32] are adjacent
+        if (tid == 0) {
+            misc[M_NEXTPOS] = 0;
+            misc[M_NTOK] = 0;
+            misc[M_OVF] = 0;
+            misc[M_CARRY] = 0;
+        }
+        uint32_t bitpos = 0;      // bits emitted so far in this unit (uniform)
+        uint32_t base_word = 0;   // output word index of stage[0] (uniform)
+        uint32_t carry_word = 0;  // partial word carried between blocks (uniform)
+        const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
+        const bool aligned = (((uintptr_t)in) & 15u) == 0;
+        __syncthreads();
+
+        // ---- close a DEFLATE block (all threads; uniform) ----
+        auto close_block = [&](const bool last_block) {
+            // ---- close a DEFLATE block ----
+            const uint32_t bfinal = (last_block && final_unit) ? 1u : 0u;
+            uint32_t *stage = (uint32_t *)(scr + S_STAGE);
+            uint32_t *lltab = (uint32_t *)(scr + S_LLTAB);
+            uint32_t *dtab = (uint32_t *)(scr + S_DTAB);
+            __syncthreads();
+            if (tid == 0) {
+                tokbuf[misc[M_NTOK]++] = 256;  // end of block
+                fl[256]++;
+            }
+            for (int i = tid; i < STAGE_WORDS; i += WG) stage[i] = 0;
+            __syncthreads();
+            if (tid == 0) stage[0] = carry_word;
+            BitW bw{stage, bitpos - base_word * 32};
+            if (P.ctype == 2) {
+                build_codes(fl, 286, 15, lltab, scr + S_HUF);
+                build_codes(fd, 30, 15, dtab, scr + S_HUF);
+                // ---- header: HLIT/HDIST, RLE of code lengths, code-length code ----
+                uint32_t *clf = (uint32_t *)(scr + S_HUF + H_CLF);      // freqs of symbols 0..18
+                uint32_t *cltab = (uint32_t *)(scr + S_HUF + H_CLTAB);
+                uint16_t *rle = (uint16_t *)(scr + S_HUF + H_RLE);      // sym | extra<<8
+                uint32_t *nrle = (uint32_t *)(scr + S_HUF + H_NRLE);
+                if (tid < 20) clf[tid] = 0;
+                __syncthreads();
+                if (tid == 0) {
+                    int hlit = 286, hdist = 30;
+                    while (hlit > 257 && (lltab[hlit - 1] >> 16) == 0) --hlit;
+                    while (hdist > 1 && (dtab[hdist - 1] >> 16) == 0) --hdist;
+                    const int tot = hlit + hdist;
+                    int nr = 0;
+                    for (int i = 0; i < tot;) {
+                        const uint32_t v = i < hlit ? lltab[i] >> 16 : dtab[i - hlit] >> 16;
+                        int run = 1;
+                        while (i + run < tot) {
+                            const int k = i + run;
+                            const uint32_t w = k < hlit ? lltab[k] >> 16 : dtab[k - hlit] >> 16;
+                            if (w != v) break;
+                            ++run;
+                        }
+                        i += run;
+                        if (v == 0) {
+                            while (run >= 11) {
+                                int r = run > 138 ? 138 : run;
+                                rle[nr++] = (uint16_t)(18 | ((r - 11) << 8));
+                                clf[18]++;
+                                run -= r;
+                            }
+                            if (run >= 3) {
+                                rle[nr++] = (uint16_t)(17 | ((run - 3) << 8));
+                                clf[17]++;
+                                run = 0;
+                            }
+                            while (run-- > 0) {
+                                rle[nr++] = 0;
+                                clf[0]++;
+                            }
+                        } else {
+                            rle[nr++] = (uint16_t)v;
+                            clf[v]++;
+                            --run;
+                            while (run >= 3) {
+                                int r = run > 6 ? 6 : run;
+                                rle[nr++] = (uint16_t)(16 | ((r - 3) << 8));
+                                clf[16]++;
+                                run -= r;
+                            }
+                            while (run-- > 0) {
+                                rle[nr++] = (uint16_t)v;
+                                clf[v]++;
+                            }
+                        }
+                    }
+                    *nrle = (uint32_t)nr | ((uint32_t)hlit << 16) | ((uint32_t)hdist << 26);
+                }
+                __syncthreads();
+                build_codes(clf, 19, 7, cltab, scr + S_HUF);
+                if (tid == 0) {
+                    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5,
+                                               11, 4, 12, 3, 13, 2, 14, 1, 15};
+                    const uint32_t pk = *nrle;
+                    const int nr = pk & 0xffff, hlit = (pk >> 16) & 0x3ff, hdist = pk >> 26;
+                    int hclen = 19;
+                    while (hclen > 4 && (cltab[order[hclen - 1]] >> 16) == 0) --hclen;
+                    bw.put(bfinal, 1);
+                    bw.put(2, 2);
+                    bw.put((uint32_t)(hlit - 257), 5);
+                    bw.put((uint32_t)(hdist - 1), 5);
+                    bw.put((uint32_t)(hclen - 4), 4);
+                    for (int i = 0; i < hclen; ++i) bw.put(cltab[order[i]] >> 16, 3);
+                    for (int i = 0; i < nr; ++i) {
+                        const uint32_t sym = rle[i] & 0xff, ex = rle[i] >> 8;
+                        bw.put(cltab[sym] & 0xffff, cltab[sym] >> 16);
+                        if (sym == 16) bw.put(ex, 2);
+                        if (sym == 17) bw.put(ex, 3);
+                        if (sym == 18) bw.put(ex, 7);
+                    }
+                    misc[M_TMP] = bw.rel;
+                }
+            } else {
+                // fixed Huffman codes (RFC 1951 3.2.6; FixedHuffmanTable rawdeflate.js:48-68)
+                if (tid < 288) {
+                    uint32_t c, l;
+                    if (tid <= 143) {
+                        c = 0x30 + tid;
+                        l = 8;
+                    } else if (tid <= 255) {
+                        c = 0x190 + tid - 144;
+                        l = 9;
+                    } else if (tid <= 279) {
+                        c = tid - 256;
+                        l = 7;
+                    } else {
+                        c = 0xc0 + tid - 280;
+                        l = 8;
+                    }
+                    lltab[tid] = (__brev(c) >> (32 - l)) | (l << 16);
+                }
+                if (tid < 32) dtab[tid] = (__brev((uint32_t)tid) >> 27) | (5u << 16);
+                if (tid == 0) {
+                    bw.put(bfinal, 1);
+                    bw.put(1, 2);
+                    misc[M_TMP] = bw.rel;
+                }
+            }
+            __syncthreads();
+            bitpos = base_word * 32 + misc[M_TMP];
+            const uint32_t ntok = misc[M_NTOK];
+            __syncthreads();
+            // ---- emit tokens ----
+            for (uint32_t t0 = 0; t0 < ntok; t0 += WG) {
+                uint64_t bits = 0;
+                uint32_t nb = 0;
+                if (t0 + tid < ntok) {
+                    const uint32_t tk = tokbuf[t0 + tid];
+                    if (!(tk & 0x80000000u)) {
+                        const uint32_t e = lltab[tk];
+                        bits = e & 0xffff;
+                        nb = e >> 16;
+                    } else {
+                        uint32_t sym, eb, ev;
+                        len_sym((tk >> 16) & 0xff, sym, eb, ev);
+                        uint32_t e = lltab[sym];
+                        bits = e & 0xffff;
+                        nb = e >> 16;
+                        bits |= (uint64_t)ev << nb;
+                        nb += eb;
+                        dist_sym(tk & 0xffff, sym, eb, ev);
+                        e = dtab[sym];
+                        bits |= (uint64_t)(e & 0xffff) << nb;
+                        nb += e >> 16;
+                        bits |= (uint64_t)ev << nb;
+                        nb += eb;
+                    }
+                }
+                uint32_t total;
+                const uint32_t off = block_scan_excl(nb, &total, misc + M_SCAN);
+                if (nb) {
+                    const uint32_t rel = bitpos + off - base_word * 32;
+                    const uint32_t w = rel >> 5, sh = rel & 31;
+                    const uint64_t lo = bits << sh;
+                    atomicOr(&stage[w], (uint32_t)lo);
+                    if ((uint32_t)(lo >> 32)) atomicOr(&stage[w + 1], (uint32_t)(lo >> 32));
+                    if (sh && (nb + sh > 64)) atomicOr(&stage[w + 2], (uint32_t)(bits >> (64 - sh)));
+                }
+                __syncthreads();
+                bitpos += total;
+                const uint32_t full = (bitpos >> 5) - base_word;
+                const bool fits = base_word + full <= cap_words;
+                if (fits)
+                    for (uint32_t i = tid; i < full; i += WG) out32[base_word + i] = stage[i];
+                else if (tid == 0)
+                    misc[M_OVF] = 1;
+                __syncthreads();
+                const uint32_t cw = stage[full];
+                __syncthreads();
+                for (uint32_t i = tid; i <= full + 2 && i < (uint32_t)STAGE_WORDS; i += WG) stage[i] = 0;
+                __syncthreads();
+                if (tid == 0) stage[0] = cw;
+                base_word += full;
+                __syncthreads();
+            }
+            carry_word = stage[0];
+            __syncthreads();
+            // reset block state
+            for (int i = tid; i < 320; i += WG) fl[i] = 0;
+            if (tid == 0) misc[M_NTOK] = 0;
+            __syncthreads();
+                };
+
+        if (n == 0) close_block(true);
+        for (uint32_t ck = 0; ck < nchunks; ++ck) {
+            const uint32_t s = ck * CHUNK;
+            // ---- load: keep the ring filled to s + 32 KiB ----
+            if ((ck & 15u) == 0) {
+                uint32_t lo = ck == 0 ? 0 : s + REFILL;
+                uint32_t hi = s + 2 * REFILL;
+                if (hi > n) hi = n;
+                if (lo < hi) {
+                    if (aligned) {
+                        uint32_t hi16 = lo + ((hi - lo) & ~15u);
+                        for (uint32_t p = lo + tid * 16; p < hi16; p += WG * 16) {
+                            uint4 v = *(const uint4 *)(in + p);
+                            uint32_t ri = p & (RING - 1);
+                            *(uint4 *)(ring + ri) = v;
+                            if (ri < RING_PAD) *(uint4 *)(ring + RING + ri) = v;
+                        }
+                        for (uint32_t p = hi16 + tid; p < hi; p += WG) {
+                            uint32_t ri = p & (RING - 1);
+                            uint8_t b = in[p];
+                            ring[ri] = b;
+                            if (ri < RING_PAD) ring[RING + ri] = b;
+                        }
+                    } else {
+                        for (uint32_t p = lo + tid; p < hi; p += WG) {
+                            uint32_t ri = p & (RING - 1);
+                            uint8_t b = in[p];
+                            ring[ri] = b;
+                            if (ri < RING_PAD) ring[RING + ri] = b;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            {
+                // ---- insert: hash, sort (hash,pos), link chains ----
+                uint32_t *sortb = (uint32_t *)(scr + S_SORT);
+                const uint32_t p = s + tid;
+                uint32_t key = 0xffffffffu;
+                if (p + 3 <= n) key = (hash3(ld4u(ring, p & (RING - 1))) << 10) | (uint32_t)tid;
+                sortb[tid] = key;
+                __syncthreads();
+                bitonic_sort(sortb, CHUNK);
+                const uint32_t e = sortb[tid];
+                const uint32_t pe = tid > 0 ? sortb[tid - 1] : 0xffffffffu;
+                const uint32_t ne = tid < CHUNK - 1 ? sortb[tid + 1] : 0xffffffffu;
+                const uint32_t h = e >> 10;
+                if (e != 0xffffffffu) {
+                    uint32_t pp = ((pe >> 10) == h) ? (s + (pe & 1023u)) : (uint32_t)head[h];
+                    prevt[(s + (e & 1023u)) & WMASK] = (uint16_t)pp;
+                }
+                __syncthreads();
+                if (e != 0xffffffffu && (ne == 0xffffffffu || (ne >> 10) != h))
+                    head[h] = (uint16_t)(s + (e & 1023u));
+                __syncthreads();
+            }
+            {
+                // ---- search: one lane per position ----
+                uint32_t *marr = (uint32_t *)(scr + S_MARR);
+                const uint32_t p = s + tid;
+                uint32_t best_len = 0, best_dist = 0;
+                if (p + 3 <= n) {
+                    const uint32_t pi = p & (RING - 1);
+                    const uint32_t maxlen = (n - p) < 258u ? (n - p) : 258u;
+                    const uint32_t limit = p < MAXDIST ? p : MAXDIST;
+                    const uint32_t pw0 = ld4u(ring, pi);
+                    uint32_t c = prevt[p & WMASK];
+                    uint32_t last = 0;
+                    uint32_t blen = 2;
+                    for (int d = 0; d < P.max_chain; ++d) {
+                        const uint32_t dist = (p - c) & 0xffffu;
+                        if (dist <= last || dist > limit) break;
+                        last = dist;
+                        const uint32_t ci = c & (RING - 1);
+                        const uint32_t x0 = ld4u(ring, ci) ^ pw0;
+                        if ((x0 & 0xffffffu) == 0 &&
+                            (blen < 3 || ring[ci + blen] == ring[pi + blen])) {
+                            uint32_t len;
+                            if (x0)
+                                len = 3;
+                            else {
+                                len = 4;
+                                while (len < maxlen) {
+                                    uint32_t x = ld4u(ring, ci + len) ^ ld4u(ring, pi + len);
+                                    if (x) {
+                                        len += (uint32_t)__builtin_ctz(x) >> 3;
+                                        break;
+                                    }
+                                    len += 4;
+                                }
+                            }
+                            if (len > maxlen) len = maxlen;
+                            if (len > blen) {
+                                blen = len;
+                                best_dist = dist;
+                                if (len >= (uint32_t)P.nice || len == maxlen) break;
+                            }
+                        }
+                        c = prevt[c & WMASK];
+                    }
+                    if (blen >= 3 && !(blen == 3 && best_dist > 4096)) best_len = blen;
+                }
+                __syncthreads();  // sort buffer (aliased) is dead for every thread
+                marr[1 + tid] = (best_len << 16) | (best_len ? best_dist - 1 : 0);
+                if (tid == 0) marr[0] = misc[M_CARRY];  // match of position s-1
+                __syncthreads();
+            }
+            {
+                // ---- parse window [s-1, s-1+W) ----
+                uint32_t *marr = (uint32_t *)(scr + S_MARR);
+                uint16_t *ja = (uint16_t *)(scr + S_JA);
+                uint16_t *jb = (uint16_t *)(scr + S_JB);
+                uint8_t *mark = scr + S_MARK;
+                const uint32_t W = (n - s) < (uint32_t)CHUNK ? (n - s) : (uint32_t)CHUNK;
+                const uint32_t nextpos = misc[M_NEXTPOS];
+                const uint32_t entry = nextpos + 1 - s;  // local index of the next token
+                uint32_t kind = 0;                       // 0 lit, 1 match here, 2 lit + match at +1
+                uint32_t adv = 1;
+                const uint32_t j = tid;
+                uint32_t m0 = 0, m1 = 0;
+                if (j < W) {
+                    m0 = marr[j];
+                    m1 = marr[j + 1];
+                    uint32_t l0 = m0 >> 16, l1 = m1 >> 16;
+                    if (j == 0 && s == 0) l0 = 0;
+                    if (l0 >= 3) {
+                        if (P.lazy > 0 && l0 < (uint32_t)P.lazy && l1 > l0) {
+                            kind = 2;
+                            adv = 1 + l1;
+                        } else {
+                            kind = 1;
+                            adv = l0;
+                        }
+                    }
+                    ja[j] = (uint16_t)(j + adv);
+                    mark[j] = (j == entry);
+                }
+                __syncthreads();
+                if (entry < W) {  // uniform
+                    uint16_t *cur = ja, *nxt = jb;
+                    for (int r = 0; r < 10; ++r) {
+                        if (j < W && mark[j]) {
+                            uint32_t t2 = cur[j];
+                            if (t2 < W) mark[t2] = 1;
+                        }
+                        if (j < W) {
+                            uint32_t t2 = cur[j];
+                            nxt[j] = t2 < W ? cur[t2] : (uint16_t)t2;
+                        }
+                        __syncthreads();
+                        uint16_t *tmp = cur;
+                        cur = nxt;
+                        nxt = tmp;
+                    }
+                    // one more marking round with the final jump table
+                    if (j < W && mark[j]) {
+                        uint32_t t2 = cur[j];
+                        if (t2 < W) mark[t2] = 1;
+                    }
+                    __syncthreads();
+                    const bool on = j < W && mark[j];
+                    const uint32_t cnt = on ? (kind == 2 ? 2u : 1u) : 0u;
+                    uint32_t total;
+                    const uint32_t off = block_scan_excl(cnt, &total, misc + M_SCAN);
+                    const uint32_t ntok = misc[M_NTOK];
+                    if (on) {
+                        const uint32_t pos = s - 1 + j;
+                        uint32_t *dst = tokbuf + ntok + off;
+                        if (kind != 1) {
+                            uint32_t b = ring[pos & (RING - 1)];
+                            *dst++ = b;
+                            atomicAdd(&fl[b], 1u);
+                        }
+                        if (kind != 0) {
+                            const uint32_t m = kind == 1 ? m0 : m1;
+                            *dst = 0x80000000u | ((m >> 16) - 3) << 16 | (m & 0xffffu);
+                            uint32_t sym, eb, ev;
+                            len_sym((m >> 16) - 3, sym, eb, ev);
+                            atomicAdd(&fl[sym], 1u);
+                            dist_sym(m & 0xffffu, sym, eb, ev);
+                            atomicAdd(&fd[sym], 1u);
+                        }
+                        if (j + adv >= W) misc[M_NEXTPOS] = s - 1 + j + adv;  // unique exit
+                    }
+                    __syncthreads();
+                    if (tid == 0) misc[M_NTOK] = ntok + total;
+                }
+                __syncthreads();
+                if (tid == 0) misc[M_CARRY] = marr[CHUNK];  // match of the last position
+                __syncthreads();
+            }
+            if (ck == nchunks - 1) {
+                // ---- epilogue: the last byte can only be a literal ----
+                if (tid == 0 && misc[M_NEXTPOS] == n - 1) {
+                    uint32_t b = ring[(n - 1) & (RING - 1)];
+                    tokbuf[misc[M_NTOK]++] = b;
+                    fl[b]++;
+                    misc[M_NEXTPOS] = n;
+                }
+                __syncthreads();
+            }
+            if ((ck % BLK_CHUNKS) != BLK_CHUNKS - 1 && ck != nchunks - 1) continue;
+            close_block(ck == nchunks - 1);
+        }
+
+        // ---- finish the unit ----
+        if (tid == 0) {
+            uint32_t bp = bitpos, cw = carry_word, bwd = base_word;
+            bool ovf = misc[M_OVF] != 0;
+            auto put = [&](uint32_t v, uint32_t nb) {
+                // serial writer straight to the output (at most a few words)
+                while (nb) {
+                    uint32_t sh = bp & 31, take = 32 - sh < nb ? 32 - sh : nb;
+                    cw |= (v & (take == 32 ? ~0u : ((1u << take) - 1))) << sh;
+                    v = take == 32 ? 0 : v >> take;
+                    nb -= take;
+                    bp += take;
+                    if ((bp & 31) == 0) {
+                        if (bwd < cap_words)
+                            out32[bwd] = cw;
+                        else
+                            ovf = true;
+                        ++bwd;
+                        cw = 0;
+                    }
+                }
+            };
+            if (sync_unit) {
+                put(0, 3);  // BFINAL=0, BTYPE=00
+                put(0, (8 - (bp & 7)) & 7);
+                put(0x0000, 16);
+                put(0xffff, 16);
+            } else
+                put(0, (8 - (bp & 7)) & 7);
+            if (bp & 31) {
+                if (bwd < cap_words)
+                    out32[bwd] = cw;
+                else
+                    ovf = true;
+            }
+            P.out_size[u] = bp >> 3;
+            P.status[u] = ovf ? 1u : 0u;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- stored blocks (CompressionType.NONE; makeNocompressBlock rawdeflate.js:131-153)
+extern "C" __global__ void __launch_bounds__(256)
+zgpu_stored_kernel(const uint8_t *in, const uint64_t *in_off, const uint64_t *slot_off,
+                   uint8_t *out_tmp, uint32_t *out_size, uint32_t *status, uint32_t n_units,
+                   uint32_t flags) {
+    for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const uint8_t *src = in + in_off[u];
+        const uint64_t n = in_off[u + 1] - in_off[u];
+        uint8_t *dst = out_tmp + slot_off[u];
+        const bool final_unit = (flags & 1u) || ((flags & 4u) && u == n_units - 1) || !(flags & 2u);
+        const uint64_t nblk = n ? (n + 65534) / 65535 : 1;
+        for (uint64_t b = 0; b < nblk; ++b) {
+            const uint64_t o = b * 65535;
+            const uint32_t len = (uint32_t)((n - o) < 65535 ? (n - o) : 65535);
+            uint8_t *d = dst + b * 65540;
+            if (threadIdx.x == 0) {
+                d[0] = (b == nblk - 1 && final_unit) ? 1 : 0;
+                d[1] = len & 0xff;
+                d[2] = len >> 8;
+                d[3] = ~len & 0xff;
+                d[4] = (~len >> 8) & 0xff;
+            }
+            for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) d[5 + i] = src[o + i];
+        }
+        if (threadIdx.x == 0) {
+            out_size[u] = (uint32_t)(n + 5 * nblk);
+            status[u] = 0;
+        }
+    }
+}
+
+// ---- exclusive scan of unit sizes -> contiguous offsets (single workgroup) --
+extern "C" __global__ void __launch_bounds__(1024)
+zgpu_scan_kernel(const uint32_t *sizes, uint64_t *out_off, uint32_t n) {
+    __shared__ unsigned long long part[16];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        unsigned long long v = i < n ? sizes[i] : 0, x = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            unsigned long long y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) part[wave] = x;
+        __syncthreads();
+        unsigned long long w = 0, tot = 0;
+        for (int k = 0; k < 16; ++k) {
+            if (k < wave) w += part[k];
+            tot += part[k];
+        }
+        const unsigned long long c = carry;
+        if (i < n) out_off[i] = c + w + x - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_off[n] = carry;
+}
+
+// ---- gather the bounded slots into one contiguous buffer -------------------
+extern "C" __global__ void __launch_bounds__(256)
+zgpu_compact_kernel(const uint8_t *out_tmp, const uint64_t *slot_off, const uint64_t *out_off,
+                    uint8_t *out, uint64_t out_cap, uint32_t *status, uint32_t n_units) {
+    for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const uint8_t *src = out_tmp + slot_off[u];
+        const uint64_t o = out_off[u], len = out_off[u + 1] - o;
+        if (o + len > out_cap) {
+            if (threadIdx.x == 0) status[u] = 2;
+            continue;
+        }
+        uint8_t *dst = out + o;
+        // byte head to a 16-byte boundary of dst, then 16-byte stores fed by
+        // unaligned-source dwords, then byte tail
+        uint64_t headb = (16 - ((uintptr_t)dst & 15)) & 15;
+        if (headb > len) headb = len;
+        for (uint64_t i = threadIdx.x; i < headb; i += blockDim.x) dst[i] = src[i];
+        const uint64_t body = (len - headb) & ~15ull;
+        const uint8_t *s2 = src + headb;
+        uint8_t *d2 = dst + headb;
+        if ((((uintptr_t)s2) & 3) == 0) {
+            for (uint64_t i = (uint64_t)threadIdx.x * 16; i < body; i += (uint64_t)blockDim.x * 16) {
+                const uint32_t *sw = (const uint32_t *)(s2 + i);
+                *(uint4 *)(d2 + i) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+            }
+        } else {
+            for (uint64_t i = (uint64_t)threadIdx.x * 16; i < body; i += (uint64_t)blockDim.x * 16) {
+                const uintptr_t a = (uintptr_t)(s2 + i);
+                const uint32_t *sw = (const uint32_t *)(a & ~(uintptr_t)3);
+                const uint32_t sh = (uint32_t)(a & 3);
+                uint32_t w0 = sw[0], w1 = sw[1], w2 = sw[2], w3 = sw[3], w4 = sw[4];
+                *(uint4 *)(d2 + i) = make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh),
+                                                __builtin_amdgcn_alignbyte(w2, w1, sh),
+                                                __builtin_amdgcn_alignbyte(w3, w2, sh),
+                                                __builtin_amdgcn_alignbyte(w4, w3, sh));
+            }
+        }
+        for (uint64_t i = headb + body + threadIdx.x; i < len; i += blockDim.x) dst[i] = src[i];
+    }
+}

@@ -1,0 +1,492 @@
+// Host side of libzgpu.so: the C ABI declared in include/zgpu.h.
+// Thin by design -- unit tables, workspace, launches and copies.  No CPU
+// compression or checksum path exists here: without a GPU every entry point
+// returns ZGPU_E_NODEVICE.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/zgpu.h"
+#include "zgpu_dev.h"
+#include "deflate_kernel.hip"
+#include "checksum_kernel.hip"
+
+namespace {
+
+thread_local int g_last_hip = 0;
+int g_max_chain = 32;
+int g_nice = 258;
+
+#define HIPCHK(expr)                         \
+    do {                                     \
+        hipError_t e_ = (expr);              \
+        if (e_ != hipSuccess) {              \
+            g_last_hip = (int)e_;            \
+            return e_ == hipErrorOutOfMemory ? ZGPU_E_NOMEM : ZGPU_E_NODEVICE; \
+        }                                    \
+    } while (0)
+
+// ---- GF(2) arithmetic for CRC-32 (reflected, bit 31 = x^0) -----------------
+constexpr uint32_t kPoly = 0xEDB88320u;
+uint32_t h_gf_mul(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; ++i) {
+        if (a & 0x80000000u) p ^= b;
+        a <<= 1;
+        b = (b >> 1) ^ ((b & 1u) ? kPoly : 0u);
+    }
+    return p;
+}
+// x^(8*nbytes) mod P
+uint32_t h_xpow_bytes(uint64_t nbytes) {
+    uint32_t r = 0x80000000u;       // x^0
+    uint32_t sq = 0x00800000u;      // x^8
+    while (nbytes) {
+        if (nbytes & 1) r = h_gf_mul(r, sq);
+        sq = h_gf_mul(sq, sq);
+        nbytes >>= 1;
+    }
+    return r;
+}
+
+struct DeviceState {
+    int device = -1;
+    int cus = 0;
+    uint32_t *d_tables = nullptr;  // checksum kernel tables
+    // scratch for zgpu_checksum_device
+    uint64_t *d_seg_off = nullptr;
+    uint32_t *d_seg_crc = nullptr, *d_seg_adler = nullptr;
+    uint64_t seg_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ck_ms = 0.f;
+};
+std::mutex g_mu;
+std::vector<DeviceState *> g_devs;
+std::vector<int> g_allowed;  // devices named by zgpu_init
+
+void build_tables(std::vector<uint32_t> &t) {
+    t.assign(20 * 256 + 8, 0);
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1) ? (kPoly ^ (c >> 1)) : (c >> 1);
+        t[i] = c;
+    }
+    for (int k = 1; k < 16; ++k)
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t p = t[(k - 1) * 256 + i];
+            t[k * 256 + i] = (p >> 8) ^ t[p & 0xff];
+        }
+    const uint32_t adv = h_xpow_bytes(16ull * ZGPU_CK_THREADS);
+    for (int j = 0; j < 4; ++j)
+        for (uint32_t v = 0; v < 256; ++v) t[(16 + j) * 256 + v] = h_gf_mul(v << (8 * j), adv);
+    for (int lv = 0; lv < 8; ++lv) t[20 * 256 + lv] = h_xpow_bytes(16ull << lv);
+}
+
+int get_state(DeviceState **out) {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto *s : g_devs)
+        if (s->device == dev) {
+            *out = s;
+            return ZGPU_OK;
+        }
+    auto *s = new (std::nothrow) DeviceState();
+    if (!s) return ZGPU_E_NOMEM;
+    s->device = dev;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    s->cus = prop.multiProcessorCount;
+    std::vector<uint32_t> t;
+    build_tables(t);
+    HIPCHK(hipMalloc(&s->d_tables, t.size() * 4));
+    HIPCHK(hipMemcpy(s->d_tables, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipEventCreate(&s->ev0));
+    HIPCHK(hipEventCreate(&s->ev1));
+    g_devs.push_back(s);
+    *out = s;
+    return ZGPU_OK;
+}
+
+uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct zgpu_plan {
+    DeviceState *ds = nullptr;
+    uint32_t n_units = 0;
+    int ctype = 2, lazy = 0;
+    uint32_t flags = 0;
+    uint64_t in_total = 0, out_bound = 0, tmp_bytes = 0;
+    uint64_t *d_in_off = nullptr, *d_slot_off = nullptr, *d_out_off = nullptr;
+    uint32_t *d_out_size = nullptr, *d_status = nullptr, *d_crc = nullptr, *d_adler = nullptr;
+    uint32_t *d_tok = nullptr, *d_counter = nullptr;
+    uint8_t *d_out_tmp = nullptr;
+    int grid = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ran = false;
+};
+
+extern "C" {
+
+int zgpu_init(const int *device_ids, int n_devices) {
+    int count = 0;
+    HIPCHK(hipGetDeviceCount(&count));
+    if (count <= 0) return ZGPU_E_NODEVICE;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_allowed.clear();
+    for (int i = 0; i < n_devices; ++i) {
+        if (device_ids[i] < 0 || device_ids[i] >= count) return ZGPU_E_ARG;
+        g_allowed.push_back(device_ids[i]);
+    }
+    return ZGPU_OK;
+}
+
+void zgpu_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto *s : g_devs) {
+        (void)hipSetDevice(s->device);
+        (void)hipFree(s->d_tables);
+        (void)hipFree(s->d_seg_off);
+        (void)hipFree(s->d_seg_crc);
+        (void)hipFree(s->d_seg_adler);
+        if (s->ev0) (void)hipEventDestroy(s->ev0);
+        if (s->ev1) (void)hipEventDestroy(s->ev1);
+        delete s;
+    }
+    g_devs.clear();
+    (void)hipSetDevice(cur);
+}
+
+const char *zgpu_strerror(int code) {
+    switch (code) {
+    case ZGPU_OK: return "ok";
+    case ZGPU_E_NODEVICE: return "no usable HIP device or HIP runtime error";
+    case ZGPU_E_ARG: return "invalid argument (e.g. invalid compression type)";
+    case ZGPU_E_NOMEM: return "out of memory";
+    case ZGPU_E_OUTCAP: return "output buffer too small";
+    case ZGPU_E_UNIT: return "a unit overflowed its output slot";
+    case ZGPU_E_TOOBIG: return "unit larger than ZGPU_MAX_UNIT_BYTES";
+    default: return "unknown error";
+    }
+}
+
+int zgpu_last_hip_error(void) { return g_last_hip; }
+
+int zgpu_set_search(int max_chain, int nice_length) {
+    if (max_chain < 1 || max_chain > 4096 || nice_length < 3 || nice_length > 258) return ZGPU_E_ARG;
+    g_max_chain = max_chain;
+    g_nice = nice_length;
+    return ZGPU_OK;
+}
+
+uint64_t zgpu_deflate_bound(uint64_t in_len) {
+    return in_len + in_len / 8 + (in_len / 65536 + 1) * 400 + 64;
+}
+
+int zgpu_plan_create(zgpu_plan **out, const uint64_t *in_off, uint32_t n_units, int ctype, int lazy,
+                     uint32_t flags) {
+    if (!out || !in_off || n_units == 0) return ZGPU_E_ARG;
+    if (ctype < 0 || ctype > 2 || lazy < 0) return ZGPU_E_ARG;
+    for (uint32_t i = 0; i < n_units; ++i) {
+        if (in_off[i + 1] < in_off[i]) return ZGPU_E_ARG;
+        if (in_off[i + 1] - in_off[i] > ZGPU_MAX_UNIT_BYTES) return ZGPU_E_TOOBIG;
+    }
+    DeviceState *ds = nullptr;
+    int rc = get_state(&ds);
+    if (rc) return rc;
+    auto *p = new (std::nothrow) zgpu_plan();
+    if (!p) return ZGPU_E_NOMEM;
+    p->ds = ds;
+    p->n_units = n_units;
+    p->ctype = ctype;
+    p->lazy = lazy;
+    p->flags = flags;
+    p->in_total = in_off[n_units];
+    std::vector<uint64_t> slot(n_units + 1);
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < n_units; ++i) {
+        slot[i] = acc;
+        acc += align_up(zgpu_deflate_bound(in_off[i + 1] - in_off[i]) + 32, 16);
+    }
+    slot[n_units] = acc;
+    p->tmp_bytes = acc;
+    p->out_bound = acc;
+    p->grid = (int)((uint64_t)ds->cus * ZGPU_DEFLATE_WG_PER_CU < n_units
+                        ? (uint64_t)ds->cus * ZGPU_DEFLATE_WG_PER_CU
+                        : n_units);
+#define PCHK(expr)                 \
+    do {                           \
+        hipError_t e_ = (expr);    \
+        if (e_ != hipSuccess) {    \
+            g_last_hip = (int)e_;  \
+            zgpu_plan_destroy(p);  \
+            return e_ == hipErrorOutOfMemory ? ZGPU_E_NOMEM : ZGPU_E_NODEVICE; \
+        }                          \
+    } while (0)
+    const size_t offb = (size_t)(n_units + 1) * 8;
+    PCHK(hipMalloc(&p->d_in_off, offb));
+    PCHK(hipMalloc(&p->d_slot_off, offb));
+    PCHK(hipMalloc(&p->d_out_off, offb));
+    PCHK(hipMalloc(&p->d_out_size, (size_t)n_units * 4));
+    PCHK(hipMalloc(&p->d_status, (size_t)n_units * 4));
+    PCHK(hipMalloc(&p->d_crc, (size_t)n_units * 4));
+    PCHK(hipMalloc(&p->d_adler, (size_t)n_units * 4));
+    PCHK(hipMalloc(&p->d_counter, 256));
+    PCHK(hipMalloc(&p->d_out_tmp, p->tmp_bytes + 64));
+    if (ctype != ZGPU_NONE) PCHK(hipMalloc(&p->d_tok, (size_t)p->grid * ZGPU_TOK_CAP * 4));
+    PCHK(hipMemcpy(p->d_in_off, in_off, offb, hipMemcpyHostToDevice));
+    PCHK(hipMemcpy(p->d_slot_off, slot.data(), offb, hipMemcpyHostToDevice));
+    PCHK(hipMemset(p->d_crc, 0, (size_t)n_units * 4));
+    PCHK(hipMemset(p->d_adler, 0, (size_t)n_units * 4));
+    for (int i = 0; i < 4; ++i) PCHK(hipEventCreate(&p->ev[i]));
+#undef PCHK
+    *out = p;
+    return ZGPU_OK;
+}
+
+void zgpu_plan_destroy(zgpu_plan *p) {
+    if (!p) return;
+    (void)hipFree(p->d_in_off);
+    (void)hipFree(p->d_slot_off);
+    (void)hipFree(p->d_out_off);
+    (void)hipFree(p->d_out_size);
+    (void)hipFree(p->d_status);
+    (void)hipFree(p->d_crc);
+    (void)hipFree(p->d_adler);
+    (void)hipFree(p->d_counter);
+    (void)hipFree(p->d_out_tmp);
+    (void)hipFree(p->d_tok);
+    for (int i = 0; i < 4; ++i)
+        if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
+    delete p;
+}
+
+uint64_t zgpu_plan_out_bound(const zgpu_plan *p) { return p ? p->out_bound : 0; }
+
+int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap, void *stream_) {
+    if (!p || !d_out || (!d_in && p->in_total)) return ZGPU_E_ARG;
+    hipStream_t st = (hipStream_t)stream_;
+    HIPCHK(hipEventRecord(p->ev[0], st));
+    HIPCHK(hipMemsetAsync(p->d_counter, 0, 4, st));
+    HIPCHK(hipEventRecord(p->ev[1], st));
+    if (p->ctype == ZGPU_NONE) {
+        int grid = p->n_units < (uint32_t)p->ds->cus * 8 ? (int)p->n_units : p->ds->cus * 8;
+        hipLaunchKernelGGL(zgpu_stored_kernel, dim3(grid), dim3(256), 0, st, (const uint8_t *)d_in,
+                           p->d_in_off, p->d_slot_off, p->d_out_tmp, p->d_out_size, p->d_status,
+                           p->n_units, p->flags);
+    } else {
+        Params P;
+        P.in = (const uint8_t *)d_in;
+        P.in_off = p->d_in_off;
+        P.slot_off = p->d_slot_off;
+        P.out_tmp = p->d_out_tmp;
+        P.out_size = p->d_out_size;
+        P.status = p->d_status;
+        P.tok = p->d_tok;
+        P.counter = p->d_counter;
+        P.n_units = p->n_units;
+        P.ctype = p->ctype;
+        P.lazy = p->lazy;
+        P.max_chain = g_max_chain;
+        P.nice = g_nice;
+        P.flags = p->flags;
+        hipLaunchKernelGGL(zgpu_deflate_kernel, dim3(p->grid), dim3(1024), 0, st, P);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(p->ev[2], st));
+    hipLaunchKernelGGL(zgpu_scan_kernel, dim3(1), dim3(1024), 0, st, p->d_out_size, p->d_out_off,
+                       p->n_units);
+    {
+        int grid = p->n_units < (uint32_t)p->ds->cus * 8 ? (int)p->n_units : p->ds->cus * 8;
+        hipLaunchKernelGGL(zgpu_compact_kernel, dim3(grid), dim3(256), 0, st, p->d_out_tmp,
+                           p->d_slot_off, p->d_out_off, (uint8_t *)d_out, out_cap, p->d_status,
+                           p->n_units);
+    }
+    if (p->flags & (ZGPU_F_WANT_CRC | ZGPU_F_WANT_ADLER)) {
+        int grid = p->n_units < (uint32_t)p->ds->cus * 8 ? (int)p->n_units : p->ds->cus * 8;
+        hipLaunchKernelGGL(zgpu_checksum_kernel, dim3(grid), dim3(ZGPU_CK_THREADS), 0, st,
+                           (const uint8_t *)d_in, p->d_in_off, p->n_units, p->ds->d_tables, p->d_crc,
+                           p->d_adler);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(p->ev[3], st));
+    p->ran = true;
+    return ZGPU_OK;
+}
+
+const uint64_t *zgpu_plan_out_off_device(const zgpu_plan *p) { return p ? p->d_out_off : nullptr; }
+const uint32_t *zgpu_plan_crc_device(const zgpu_plan *p) { return p ? p->d_crc : nullptr; }
+const uint32_t *zgpu_plan_adler_device(const zgpu_plan *p) { return p ? p->d_adler : nullptr; }
+
+int zgpu_plan_fetch(zgpu_plan *p, uint64_t *out_off, uint32_t *crc32, uint32_t *adler32, void *stream_) {
+    if (!p || !p->ran) return ZGPU_E_ARG;
+    hipStream_t st = (hipStream_t)stream_;
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<uint32_t> status(p->n_units);
+    HIPCHK(hipMemcpy(status.data(), p->d_status, (size_t)p->n_units * 4, hipMemcpyDeviceToHost));
+    if (out_off)
+        HIPCHK(hipMemcpy(out_off, p->d_out_off, (size_t)(p->n_units + 1) * 8, hipMemcpyDeviceToHost));
+    if (crc32) HIPCHK(hipMemcpy(crc32, p->d_crc, (size_t)p->n_units * 4, hipMemcpyDeviceToHost));
+    if (adler32) HIPCHK(hipMemcpy(adler32, p->d_adler, (size_t)p->n_units * 4, hipMemcpyDeviceToHost));
+    int rc = ZGPU_OK;
+    for (uint32_t i = 0; i < p->n_units; ++i) {
+        if (status[i] == 2) rc = ZGPU_E_OUTCAP;
+        else if (status[i] && rc == ZGPU_OK) rc = ZGPU_E_UNIT;
+    }
+    return rc;
+}
+
+int zgpu_plan_kernel_ms(zgpu_plan *p, float *deflate_ms, float *total_ms) {
+    if (!p || !p->ran) return ZGPU_E_ARG;
+    HIPCHK(hipEventSynchronize(p->ev[3]));
+    if (deflate_ms) HIPCHK(hipEventElapsedTime(deflate_ms, p->ev[1], p->ev[2]));
+    if (total_ms) HIPCHK(hipEventElapsedTime(total_ms, p->ev[0], p->ev[3]));
+    return ZGPU_OK;
+}
+
+int zgpu_deflate_batch(const uint8_t *in, const uint64_t *in_off, uint32_t n_units, int ctype, int lazy,
+                       uint32_t flags, uint8_t *out, uint64_t out_cap, uint64_t *out_off,
+                       uint32_t *crc32, uint32_t *adler32) {
+    if (!in_off || !out || !out_off) return ZGPU_E_ARG;
+    if (crc32) flags |= ZGPU_F_WANT_CRC;
+    if (adler32) flags |= ZGPU_F_WANT_ADLER;
+    zgpu_plan *p = nullptr;
+    int rc = zgpu_plan_create(&p, in_off, n_units, ctype, lazy, flags);
+    if (rc) return rc;
+    const uint64_t base = in_off[0], total = in_off[n_units] - base;
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    auto fail = [&](int code) {
+        (void)hipFree(d_in);
+        (void)hipFree(d_out);
+        zgpu_plan_destroy(p);
+        return code;
+    };
+    hipError_t e;
+    // the plan indexes d_in with the caller's absolute offsets
+    if ((e = hipMalloc(&d_in, in_off[n_units] + 64)) != hipSuccess) { g_last_hip = e; return fail(ZGPU_E_NOMEM); }
+    if ((e = hipMalloc(&d_out, p->out_bound + 64)) != hipSuccess) { g_last_hip = e; return fail(ZGPU_E_NOMEM); }
+    if (total && (e = hipMemcpy(d_in + base, in + base, total, hipMemcpyHostToDevice)) != hipSuccess) {
+        g_last_hip = e;
+        return fail(ZGPU_E_NODEVICE);
+    }
+    rc = zgpu_plan_run(p, d_in, d_out, p->out_bound, nullptr);
+    if (rc) return fail(rc);
+    rc = zgpu_plan_fetch(p, out_off, crc32, adler32, nullptr);
+    if (rc) return fail(rc);
+    if (out_off[n_units] > out_cap) return fail(ZGPU_E_OUTCAP);
+    if (out_off[n_units] &&
+        (e = hipMemcpy(out, d_out, out_off[n_units], hipMemcpyDeviceToHost)) != hipSuccess) {
+        g_last_hip = e;
+        return fail(ZGPU_E_NODEVICE);
+    }
+    return fail(ZGPU_OK);
+}
+
+// ---- checksums -------------------------------------------------------------
+uint32_t zgpu_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
+    return h_gf_mul(crc_a, h_xpow_bytes(len_b)) ^ crc_b;
+}
+
+uint32_t zgpu_adler32_combine(uint32_t a, uint32_t b, uint64_t len_b) {
+    const uint32_t M = 65521u;
+    const uint64_t rem = len_b % M;
+    uint64_t s1a = a & 0xffff, s2a = a >> 16, s1b = b & 0xffff, s2b = b >> 16;
+    // s1 = s1a + s1b - 1 ; s2 = s2a + s2b + len_b*(s1a - 1)
+    uint64_t s1 = (s1a + s1b + M - 1) % M;
+    uint64_t s2 = (s2a + s2b + rem * ((s1a + M - 1) % M)) % M;
+    return (uint32_t)((s2 << 16) | s1);
+}
+
+int zgpu_checksum_device(const void *d_in, uint64_t len, uint32_t *crc32, uint32_t *adler32,
+                         void *stream_) {
+    DeviceState *ds = nullptr;
+    int rc = get_state(&ds);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream_;
+    const uint64_t nseg = len ? (len + ZGPU_CK_SEG - 1) / ZGPU_CK_SEG : 1;
+    if (nseg + 1 > ds->seg_cap) {
+        (void)hipFree(ds->d_seg_off);
+        (void)hipFree(ds->d_seg_crc);
+        (void)hipFree(ds->d_seg_adler);
+        ds->seg_cap = 0;
+        HIPCHK(hipMalloc(&ds->d_seg_off, (nseg + 1) * 8));
+        HIPCHK(hipMalloc(&ds->d_seg_crc, nseg * 4));
+        HIPCHK(hipMalloc(&ds->d_seg_adler, nseg * 4));
+        ds->seg_cap = nseg + 1;
+    }
+    std::vector<uint64_t> off(nseg + 1);
+    for (uint64_t i = 0; i < nseg; ++i) off[i] = i * (uint64_t)ZGPU_CK_SEG;
+    off[nseg] = len;
+    HIPCHK(hipMemcpyAsync(ds->d_seg_off, off.data(), (nseg + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // off is a local
+    const int grid = (int)(nseg < (uint64_t)ds->cus * 8 ? nseg : (uint64_t)ds->cus * 8);
+    HIPCHK(hipEventRecord(ds->ev0, st));
+    hipLaunchKernelGGL(zgpu_checksum_kernel, dim3(grid), dim3(ZGPU_CK_THREADS), 0, st,
+                       (const uint8_t *)d_in, ds->d_seg_off, (uint32_t)nseg, ds->d_tables,
+                       ds->d_seg_crc, ds->d_seg_adler);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ds->ev1, st));
+    std::vector<uint32_t> c(nseg), a(nseg);
+    HIPCHK(hipMemcpyAsync(c.data(), ds->d_seg_crc, nseg * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a.data(), ds->d_seg_adler, nseg * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipEventElapsedTime(&ds->last_ck_ms, ds->ev0, ds->ev1));
+    uint32_t crc = c[0], ad = a[0];
+    const uint32_t xs = h_xpow_bytes(ZGPU_CK_SEG);
+    for (uint64_t i = 1; i < nseg; ++i) {
+        const uint64_t l = off[i + 1] - off[i];
+        crc = h_gf_mul(crc, l == ZGPU_CK_SEG ? xs : h_xpow_bytes(l)) ^ c[i];
+        ad = zgpu_adler32_combine(ad, a[i], l);
+    }
+    if (crc32) *crc32 = crc;
+    if (adler32) *adler32 = ad;
+    return ZGPU_OK;
+}
+
+int zgpu_checksum_kernel_ms(float *ms) {
+    DeviceState *ds = nullptr;
+    int rc = get_state(&ds);
+    if (rc) return rc;
+    if (ms) *ms = ds->last_ck_ms;
+    return ZGPU_OK;
+}
+
+int zgpu_checksum(const uint8_t *in, uint64_t len, uint32_t *crc32, uint32_t *adler32) {
+    if (!in && len) return ZGPU_E_ARG;
+    uint8_t *d = nullptr;
+    HIPCHK(hipMalloc(&d, len + 64));
+    hipError_t e = len ? hipMemcpy(d, in, len, hipMemcpyHostToDevice) : hipSuccess;
+    if (e != hipSuccess) {
+        g_last_hip = e;
+        (void)hipFree(d);
+        return ZGPU_E_NODEVICE;
+    }
+    int rc = zgpu_checksum_device(d, len, crc32, adler32, nullptr);
+    (void)hipFree(d);
+    return rc;
+}
+
+int zgpu_crc32_update(const uint8_t *in, uint64_t len, uint32_t crc, uint32_t *out) {
+    uint32_t c = 0;
+    int rc = zgpu_checksum(in, len, &c, nullptr);
+    if (rc) return rc;
+    if (out) *out = zgpu_crc32_combine(crc, c, len);
+    return ZGPU_OK;
+}
+
+int zgpu_adler32_update(const uint8_t *in, uint64_t len, uint32_t adler, uint32_t *out) {
+    uint32_t a = 1;
+    int rc = zgpu_checksum(in, len, nullptr, &a);
+    if (rc) return rc;
+    if (out) *out = zgpu_adler32_combine(adler, a, len);
+    return ZGPU_OK;
+}
+
+}  // extern "C"
