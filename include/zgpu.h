@@ -63,6 +63,11 @@ const char *zgpu_strerror(int code);
 int zgpu_last_hip_error(void);
 /* engine knobs: hash-chain search depth and "good enough" match length */
 int zgpu_set_search(int max_chain, int nice_length);
+/* The parse defers a match shorter than max(lazy, min_lazy) by one position
+ * when the next position matches longer (the reference's `lazy` rule,
+ * src/rawdeflate.js:339-347, applied from min_lazy even when lazy is 0).
+ * 0 restores the reference's pure greedy parse for lazy = 0.  Default 258. */
+int zgpu_set_min_lazy(int min_lazy);
 
 /* ---- sizing ------------------------------------------------------------- */
 /* Worst-case compressed size of one unit of in_len bytes for any

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of the DEFLATE kernel (diagnostic build
+libzgpu_prof.so: `make -C zlib.es_amd/csrc prof`).  Prints, per content kind,
+thread-0 cycles per input byte spent in each phase."""
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["ZGPU_LIB"] = os.path.join(ROOT, "zlib.es_amd", "libzgpu_prof.so")
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import zlib_es_amd as z  # noqa: E402
+
+PHASES = ["load", "insert", "search", "wait", "parse", "codes+hdr", "emit", "-"]
+
+
+def run(name, data, nu, ub, ctype, lazy):
+    L = z._native.lib()
+    L.zgpu_prof_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    in_off = np.arange(nu + 1, dtype=np.uint64) * np.uint64(ub)
+    plan = z.Plan(in_off, ctype, lazy, 1)
+    out = torch.empty(plan.out_bound + 64, dtype=torch.uint8, device="cuda")
+    prof = np.zeros(8, dtype=np.uint64)
+    L.zgpu_prof_read(prof.ctypes.data, 1)
+    plan.run(data.data_ptr(), out.data_ptr(), out.numel(), None)
+    torch.cuda.synchronize()
+    L.zgpu_prof_read(prof.ctypes.data, 1)
+    t0 = time.perf_counter()
+    plan.run(data.data_ptr(), out.data_ptr(), out.numel(), None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    L.zgpu_prof_read(prof.ctypes.data, 1)
+    off, _, _ = plan.fetch()
+    nbytes = nu * ub
+    per = prof.astype(np.float64) / nbytes
+    print("%-8s %7.2f GB/s ratio %.4f | cyc/B: %s | total %.1f" % (
+        name, nbytes / dt / 1e9, int(off[-1]) / nbytes,
+        " ".join("%s=%.1f" % (p, v) for p, v in zip(PHASES[:7], per[:7])), per.sum()), flush=True)
+
+
+def main():
+    nu, ub = int(os.environ.get("NU", 2048)), int(os.environ.get("UB", 65536))
+    chain = int(os.environ.get("CHAIN", 32))
+    z.set_search(chain, 258)
+    dev = torch.device("cuda")
+    full = bench.gen_units(20 * 512, ub, 7, dev).view(-1, ub)
+    kinds = {"text": (0, 10), "binary": (10, 15), "random": (15, 18), "lowent": (18, 20)}
+    idx = torch.arange(full.shape[0], device=dev) % 20
+    for name, (a, b) in kinds.items():
+        rows = full[(idx >= a) & (idx < b)][:nu].contiguous()
+        n = rows.shape[0]
+        run(name, rows.view(-1), n, ub, 2, 0)
+    mixed = full[:nu].contiguous()
+    run("mixed", mixed.view(-1), mixed.shape[0], ub, 2, 0)
+    run("mixed-fx", mixed.view(-1), mixed.shape[0], ub, 1, 0)
+    run("mixed-lz", mixed.view(-1), mixed.shape[0], ub, 2, 16)
+
+
+if __name__ == "__main__":
+    main()

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzgpu.so")
+# ZGPU_LIB selects a diagnostic build (e.g. libzgpu_prof.so); the default is the product library
+LIB_PATH = os.environ.get("ZGPU_LIB") or os.path.join(_HERE, "libzgpu.so")
 
 NONE, FIXED, DYNAMIC = 0, 1, 2
 F_FINAL_EACH, F_SYNC_ALIGN, F_FINAL_LAST, F_WANT_CRC, F_WANT_ADLER = 1, 2, 4, 16, 32
@@ -17,6 +18,7 @@ F_FINAL_EACH, F_SYNC_ALIGN, F_FINAL_LAST, F_WANT_CRC, F_WANT_ADLER = 1, 2, 4, 16
 # every symbol include/zgpu.h declares
 SYMBOLS = [
     "zgpu_init", "zgpu_shutdown", "zgpu_strerror", "zgpu_last_hip_error", "zgpu_set_search",
+    "zgpu_set_min_lazy",
     "zgpu_deflate_bound", "zgpu_deflate_batch", "zgpu_plan_create", "zgpu_plan_destroy",
     "zgpu_plan_out_bound", "zgpu_plan_run", "zgpu_plan_out_off_device", "zgpu_plan_crc_device",
     "zgpu_plan_adler_device", "zgpu_plan_fetch", "zgpu_plan_kernel_ms", "zgpu_checksum",
@@ -53,6 +55,8 @@ def lib():
     L.zgpu_last_hip_error.restype = i32
     L.zgpu_set_search.restype = i32
     L.zgpu_set_search.argtypes = [i32, i32]
+    L.zgpu_set_min_lazy.restype = i32
+    L.zgpu_set_min_lazy.argtypes = [i32]
     L.zgpu_deflate_bound.restype = u64
     L.zgpu_deflate_bound.argtypes = [u64]
     L.zgpu_deflate_batch.restype = i32
@@ -107,6 +111,10 @@ def deflate_bound(n):
 
 def set_search(max_chain, nice_length=258):
     _check(lib().zgpu_set_search(max_chain, nice_length), "zgpu_set_search")
+
+
+def set_min_lazy(min_lazy):
+    _check(lib().zgpu_set_min_lazy(min_lazy), "zgpu_set_min_lazy")
 
 
 def crc32_combine(a, b, len_b):

@@ -24,6 +24,19 @@
 
 namespace {
 
+// Optional per-phase cycle counters (diagnostic build only: -DZGPU_PROFILE).
+#ifdef ZGPU_PROFILE
+#define PH_DECL unsigned long long ph_t0 = 0, ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PH_START() do { if (tid == 0) ph_t0 = clock64(); } while (0)
+#define PH_END(i) do { if (tid == 0) { unsigned long long t_ = clock64(); ph_acc[i] += t_ - ph_t0; ph_t0 = t_; } } while (0)
+#define PH_FLUSH() do { if (tid == 0 && P.prof) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&P.prof[i_], ph_acc[i_]); } while (0)
+#else
+#define PH_DECL
+#define PH_START()
+#define PH_END(i)
+#define PH_FLUSH()
+#endif
+
 constexpr int WG = 1024;
 constexpr int CHUNK = 1024;         // positions inserted/searched per step
 constexpr int HBITS = 13;           // hash-head table entries = 1 << HBITS
@@ -33,6 +46,9 @@ constexpr uint32_t WMASK = 0x7fff;  // chain slots (32 Ki positions)
 constexpr uint32_t MAXDIST = 32768 - CHUNK;
 constexpr int BLK_CHUNKS = 64;      // one DEFLATE block per 64 KiB of input
 constexpr uint32_t REFILL = 16384;  // ring refill granule
+constexpr uint32_t CMP_CAP = 32;   // pass-1 compare length cap (bytes)
+constexpr uint32_t SHARE_MIN = 16;  // matches at least this long offer their distance to the wave
+constexpr int SHARE_ITERS = 6;      // distinct distances scored per wave
 constexpr int STAGE_WORDS = 1792;   // bit staging (>= header + 1024*48/32 + carry)
 
 // ---- LDS map (bytes) -------------------------------------------------------
@@ -73,7 +89,8 @@ constexpr uint32_t H_NRLE = 5568;    // u32
 static_assert(HUF_BYTES >= 5572, "huffman scratch");
 
 // misc words
-enum { M_SCAN = 0 /*[32]*/, M_UNIT = 32, M_NEXTPOS = 33, M_NTOK = 34, M_TMP = 35, M_OVF = 36, M_CARRY = 37 };
+enum { M_SCAN = 0 /*[16]*/, M_WCNT = 16 /*[16]*/, M_UNIT = 32, M_NEXTPOS = 33, M_NTOK = 34, M_TMP = 35, M_OVF = 36,
+       M_CARRY = 37, M_TURN = 38 };
 
 struct Lds {
     uint8_t *base;
@@ -139,6 +156,38 @@ __device__ inline void bitonic_sort(uint32_t *a, int n) {
             __syncthreads();
         }
     }
+}
+
+// Wave-to-wave hand-off through one LDS word.  LDS operations of a wave are
+// issued and completed in order and the LDS is a single coherent memory for
+// the workgroup, so a wave that has drained its own LDS queue (lgkmcnt(0)) may
+// publish, and a wave that has seen the value may read what was written before
+// it.  Only LDS is ordered here: no global-memory fence is involved.
+__device__ inline void lds_wait_eq(uint32_t *word, uint32_t want) {
+    volatile uint32_t *w = word;
+    while (*w != want) __builtin_amdgcn_s_sleep(0);
+    asm volatile("" ::: "memory");
+}
+__device__ inline void lds_publish(uint32_t *word, uint32_t value) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) *(volatile uint32_t *)word = value;
+}
+
+// bitonic sort of one key per lane across the wave (ascending by lane), in registers
+__device__ inline uint32_t wave_sort64(uint32_t key) {
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (uint32_t k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t other = __shfl_xor(key, (int)j, 64);
+            const bool up = (lane & k) == 0;
+            const bool lower = (lane & j) == 0;
+            const uint32_t mn = key < other ? key : other, mx = key < other ? other : key;
+            key = (lower == up) ? mn : mx;
+        }
+    }
+    return key;
 }
 
 // RFC 1951 length symbol for l = len-3 (0..255): symbol, extra bit count, extra value
@@ -300,6 +349,7 @@ struct Params {
     uint32_t n_units;
     int ctype, lazy, max_chain, nice;
     uint32_t flags;
+    unsigned long long *prof;  // 8 phase counters (diagnostic builds) or null
 };
 
 }  // namespace
@@ -308,13 +358,14 @@ extern "C" __global__ void __launch_bounds__(WG)
 zgpu_deflate_kernel(Params P) {
     __shared__ __align__(16) uint8_t lds_raw[L_TOTAL];
     Lds L{lds_raw};
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t *ring = L.ring();
     uint16_t *prevt = L.prev();
     uint16_t *head = L.head();
     uint32_t *fl = L.fl(), *fd = L.fd(), *misc = L.misc();
     uint8_t *scr = L.scr();
     uint32_t *tokbuf = P.tok + (size_t)blockIdx.x * ZGPU_TOK_CAP;
+    PH_DECL;
 
     for (;;) {
         if (tid == 0) misc[M_UNIT] = atomicAdd(P.counter, 1u);
@@ -340,6 +391,7 @@ zgpu_deflate_kernel(Params P) {
             misc[M_NTOK] = 0;
             misc[M_OVF] = 0;
             misc[M_CARRY] = 0;
+            misc[M_TURN] = 0;
         }
         uint32_t bitpos = 0;      // bits emitted so far in this unit (uniform)
         uint32_t base_word = 0;   // output word index of stage[0] (uniform)
@@ -350,6 +402,7 @@ zgpu_deflate_kernel(Params P) {
 
         // ---- close a DEFLATE block (all threads; uniform) ----
         auto close_block = [&](const bool last_block) {
+            PH_START();
             // ---- close a DEFLATE block ----
             const uint32_t bfinal = (last_block && final_unit) ? 1u : 0u;
             uint32_t *stage = (uint32_t *)(scr + S_STAGE);
@@ -478,6 +531,7 @@ zgpu_deflate_kernel(Params P) {
             bitpos = base_word * 32 + misc[M_TMP];
             const uint32_t ntok = misc[M_NTOK];
             __syncthreads();
+            PH_END(5);
             // ---- emit tokens ----
             for (uint32_t t0 = 0; t0 < ntok; t0 += WG) {
                 uint64_t bits = 0;
@@ -531,6 +585,7 @@ zgpu_deflate_kernel(Params P) {
                 base_word += full;
                 __syncthreads();
             }
+            PH_END(6);
             carry_word = stage[0];
             __syncthreads();
             // reset block state
@@ -542,6 +597,7 @@ zgpu_deflate_kernel(Params P) {
         if (n == 0) close_block(true);
         for (uint32_t ck = 0; ck < nchunks; ++ck) {
             const uint32_t s = ck * CHUNK;
+            PH_START();
             // ---- load: keep the ring filled to s + 32 KiB ----
             if ((ck & 15u) == 0) {
                 uint32_t lo = ck == 0 ? 0 : s + REFILL;
@@ -573,42 +629,54 @@ zgpu_deflate_kernel(Params P) {
                 }
                 __syncthreads();
             }
+            PH_END(0);
             {
-                // ---- insert: hash, sort (hash,pos), link chains ----
-                uint32_t *sortb = (uint32_t *)(scr + S_SORT);
+                // ---- insert: per-wave sort of (hash, lane), chains linked wave after wave ----
+                // Wave w owns positions [s+64w, s+64w+64).  Its lanes sort their
+                // (hash<<6 | lane) keys in registers; equal hashes become adjacent, which
+                // gives every element its predecessor inside the wave.  The first element
+                // of each hash run links to head[hash]; the last one becomes the new head.
+                // Waves take turns in position order (a ticket in LDS), so head[] always
+                // holds the latest earlier position when a wave reads it.
                 const uint32_t p = s + tid;
                 uint32_t key = 0xffffffffu;
-                if (p + 3 <= n) key = (hash3(ld4u(ring, p & (RING - 1))) << 10) | (uint32_t)tid;
-                sortb[tid] = key;
-                __syncthreads();
-                bitonic_sort(sortb, CHUNK);
-                const uint32_t e = sortb[tid];
-                const uint32_t pe = tid > 0 ? sortb[tid - 1] : 0xffffffffu;
-                const uint32_t ne = tid < CHUNK - 1 ? sortb[tid + 1] : 0xffffffffu;
-                const uint32_t h = e >> 10;
-                if (e != 0xffffffffu) {
-                    uint32_t pp = ((pe >> 10) == h) ? (s + (pe & 1023u)) : (uint32_t)head[h];
-                    prevt[(s + (e & 1023u)) & WMASK] = (uint16_t)pp;
+                if (p + 3 <= n) key = (hash3(ld4u(ring, p & (RING - 1))) << 6) | (uint32_t)lane;
+                key = wave_sort64(key);
+                const uint32_t kp = __shfl_up(key, 1, 64), kn = __shfl_down(key, 1, 64);
+                const uint32_t h = key >> 6;
+                const bool live = key != 0xffffffffu;
+                const bool first = lane == 0 || (kp >> 6) != h;
+                const bool last = lane == 63 || (kn >> 6) != h || kn == 0xffffffffu;
+                const uint32_t mypos = s + (uint32_t)(wave << 6) + (key & 63u);
+                const uint32_t ticket = ck * (WG / 64) + (uint32_t)wave;
+                lds_wait_eq(&misc[M_TURN], ticket);
+                if (live) {
+                    const uint32_t pp = first ? (uint32_t)head[h]
+                                              : (s + (uint32_t)(wave << 6) + (kp & 63u));
+                    prevt[mypos & WMASK] = (uint16_t)pp;
                 }
-                __syncthreads();
-                if (e != 0xffffffffu && (ne == 0xffffffffu || (ne >> 10) != h))
-                    head[h] = (uint16_t)(s + (e & 1023u));
-                __syncthreads();
+                if (live && last) head[h] = (uint16_t)mypos;
+                lds_publish(&misc[M_TURN], ticket + 1);
+                PH_END(1);
             }
             {
-                // ---- search: one lane per position ----
+                // ---- search: one lane per position (candidates lie in this or earlier waves) ----
                 uint32_t *marr = (uint32_t *)(scr + S_MARR);
                 const uint32_t p = s + tid;
                 uint32_t best_len = 0, best_dist = 0;
+                const uint32_t maxlen = p < n ? ((n - p) < 258u ? (n - p) : 258u) : 0u;
+                uint32_t blen = 2;
                 if (p + 3 <= n) {
+                    // pass 1, lane per position: walk the hash chain; compares stop at
+                    // CMP_CAP bytes so that every lane's work is bounded
                     const uint32_t pi = p & (RING - 1);
-                    const uint32_t maxlen = (n - p) < 258u ? (n - p) : 258u;
+                    const uint32_t cmpmax = maxlen < CMP_CAP ? maxlen : CMP_CAP;
+                    const uint32_t stop = cmpmax < (uint32_t)P.nice ? cmpmax : (uint32_t)P.nice;
                     const uint32_t limit = p < MAXDIST ? p : MAXDIST;
                     const uint32_t pw0 = ld4u(ring, pi);
                     uint32_t c = prevt[p & WMASK];
                     uint32_t last = 0;
-                    uint32_t blen = 2;
-                    for (int d = 0; d < P.max_chain; ++d) {
+                    for (int budget = P.max_chain; budget > 0; --budget) {
                         const uint32_t dist = (p - c) & 0xffffu;
                         if (dist <= last || dist > limit) break;
                         last = dist;
@@ -621,7 +689,7 @@ zgpu_deflate_kernel(Params P) {
                                 len = 3;
                             else {
                                 len = 4;
-                                while (len < maxlen) {
+                                while (len < cmpmax) {
                                     uint32_t x = ld4u(ring, ci + len) ^ ld4u(ring, pi + len);
                                     if (x) {
                                         len += (uint32_t)__builtin_ctz(x) >> 3;
@@ -630,106 +698,172 @@ zgpu_deflate_kernel(Params P) {
                                     len += 4;
                                 }
                             }
-                            if (len > maxlen) len = maxlen;
+                            if (len > cmpmax) len = cmpmax;
                             if (len > blen) {
                                 blen = len;
                                 best_dist = dist;
-                                if (len >= (uint32_t)P.nice || len == maxlen) break;
+                                if (len >= stop) break;
                             }
                         }
                         c = prevt[c & WMASK];
                     }
-                    if (blen >= 3 && !(blen == 3 && best_dist > 4096)) best_len = blen;
                 }
-                __syncthreads();  // sort buffer (aliased) is dead for every thread
+                {
+                    // pass 2, distance sharing across the wave: a distance that gave one
+                    // lane a long match is scored for all 64 positions at once -- one byte
+                    // compare per lane, a ballot, and count-trailing-ones give every lane
+                    // its exact match length (up to 258) at that distance.
+                    const uint32_t p0 = s + ((uint32_t)wave << 6);
+                    const uint32_t offer = best_dist;
+                    unsigned long long todo = __ballot(blen >= SHARE_MIN);
+                    for (int it = 0; it < SHARE_ITERS && todo; ++it) {
+                        const int src = __builtin_ctzll(todo);
+                        const uint32_t d = (uint32_t)__shfl((int)offer, src, 64);
+                        uint32_t run = 0;
+                        bool open = true;
+                        for (uint32_t w = 0; w < 6; ++w) {
+                            const uint32_t q = p0 + (w << 6) + (uint32_t)lane;
+                            const bool eq = q < n && q >= d &&
+                                            ring[q & (RING - 1)] == ring[(q - d) & (RING - 1)];
+                            const unsigned long long m = __ballot(eq);
+                            if (w == 0) {
+                                const unsigned long long inv = ~(m >> lane);
+                                // ones shifted in above bit 63-lane read as mismatches after the inversion
+                                run = inv ? (uint32_t)__builtin_ctzll(inv) : 64u;
+                                if (run > 64u - (uint32_t)lane) run = 64u - (uint32_t)lane;
+                                open = run == 64u - (uint32_t)lane;
+                            } else if (open) {
+                                const uint32_t r2 = ~m ? (uint32_t)__builtin_ctzll(~m) : 64u;
+                                run += r2;
+                                open = r2 == 64u;
+                            }
+                            if (!__ballot(open && run < 258u)) break;
+                        }
+                        if (run > maxlen) run = maxlen;
+                        if (run >= 3 && d <= (p < MAXDIST ? p : MAXDIST) &&
+                            (run > blen || (run == blen && d < best_dist))) {
+                            blen = run;
+                            best_dist = d;
+                        }
+                        todo &= ~__ballot(offer == d);
+                    }
+                }
+                if (blen >= 3 && !(blen == 3 && best_dist > 4096)) best_len = blen;
                 marr[1 + tid] = (best_len << 16) | (best_len ? best_dist - 1 : 0);
                 if (tid == 0) marr[0] = misc[M_CARRY];  // match of position s-1
-                __syncthreads();
+                PH_END(2);
+                __syncthreads();  // A: every match of this chunk is in marr
+                PH_END(3);
             }
             {
-                // ---- parse window [s-1, s-1+W) ----
+                // ---- parse window [s-1, s-1+W): window index j <-> position s-1+j ----
+                // Wave w resolves indices [64w, 64w+64) in registers: successor per index,
+                // six pointer-doubling steps by lane shuffles give the exit of every index,
+                // the entry of each segment follows by walking the exits of the earlier
+                // segments, and the k-th token of a segment is found by composing the
+                // doubling tables along the bits of k (tokens come out already compacted).
                 uint32_t *marr = (uint32_t *)(scr + S_MARR);
-                uint16_t *ja = (uint16_t *)(scr + S_JA);
-                uint16_t *jb = (uint16_t *)(scr + S_JB);
-                uint8_t *mark = scr + S_MARK;
+                uint16_t *exitv = (uint16_t *)(scr + S_JA);
+                uint8_t *kindv = scr + S_MARK;
+                uint32_t *wcnt = misc + M_WCNT;
                 const uint32_t W = (n - s) < (uint32_t)CHUNK ? (n - s) : (uint32_t)CHUNK;
-                const uint32_t nextpos = misc[M_NEXTPOS];
-                const uint32_t entry = nextpos + 1 - s;  // local index of the next token
-                uint32_t kind = 0;                       // 0 lit, 1 match here, 2 lit + match at +1
-                uint32_t adv = 1;
+                const uint32_t entry0 = misc[M_NEXTPOS] + 1 - s;  // window index of the next token
+                const uint32_t ntok0 = misc[M_NTOK];
+                const uint32_t seg_base = (uint32_t)wave << 6;
+                const uint32_t seg_end = seg_base + 64 < W ? seg_base + 64 : W;
                 const uint32_t j = tid;
-                uint32_t m0 = 0, m1 = 0;
-                if (j < W) {
-                    m0 = marr[j];
-                    m1 = marr[j + 1];
-                    uint32_t l0 = m0 >> 16, l1 = m1 >> 16;
-                    if (j == 0 && s == 0) l0 = 0;
-                    if (l0 >= 3) {
-                        if (P.lazy > 0 && l0 < (uint32_t)P.lazy && l1 > l0) {
-                            kind = 2;
-                            adv = 1 + l1;
-                        } else {
-                            kind = 1;
-                            adv = l0;
+                uint32_t J[7];
+                {
+                    uint32_t kind = 0, adv = 1;  // 0 literal, 1 match here, 2 literal + match at +1
+                    if (j < W) {
+                        const uint32_t m0 = marr[j], m1 = marr[j + 1];
+                        uint32_t l0 = m0 >> 16;
+                        const uint32_t l1 = m1 >> 16;
+                        if (j == 0 && s == 0) l0 = 0;
+                        if (l0 >= 3) {
+                            if (P.lazy > 0 && l0 < (uint32_t)P.lazy && l1 > l0) {
+                                kind = 2;
+                                adv = 1 + l1;
+                            } else {
+                                kind = 1;
+                                adv = l0;
+                            }
                         }
+                        kindv[j] = (uint8_t)kind;
                     }
-                    ja[j] = (uint16_t)(j + adv);
-                    mark[j] = (j == entry);
+                    J[0] = j + adv;
                 }
-                __syncthreads();
-                if (entry < W) {  // uniform
-                    uint16_t *cur = ja, *nxt = jb;
-                    for (int r = 0; r < 10; ++r) {
-                        if (j < W && mark[j]) {
-                            uint32_t t2 = cur[j];
-                            if (t2 < W) mark[t2] = 1;
-                        }
-                        if (j < W) {
-                            uint32_t t2 = cur[j];
-                            nxt[j] = t2 < W ? cur[t2] : (uint16_t)t2;
-                        }
-                        __syncthreads();
-                        uint16_t *tmp = cur;
-                        cur = nxt;
-                        nxt = tmp;
-                    }
-                    // one more marking round with the final jump table
-                    if (j < W && mark[j]) {
-                        uint32_t t2 = cur[j];
-                        if (t2 < W) mark[t2] = 1;
-                    }
-                    __syncthreads();
-                    const bool on = j < W && mark[j];
-                    const uint32_t cnt = on ? (kind == 2 ? 2u : 1u) : 0u;
-                    uint32_t total;
-                    const uint32_t off = block_scan_excl(cnt, &total, misc + M_SCAN);
-                    const uint32_t ntok = misc[M_NTOK];
-                    if (on) {
-                        const uint32_t pos = s - 1 + j;
-                        uint32_t *dst = tokbuf + ntok + off;
-                        if (kind != 1) {
-                            uint32_t b = ring[pos & (RING - 1)];
-                            *dst++ = b;
-                            atomicAdd(&fl[b], 1u);
-                        }
-                        if (kind != 0) {
-                            const uint32_t m = kind == 1 ? m0 : m1;
-                            *dst = 0x80000000u | ((m >> 16) - 3) << 16 | (m & 0xffffu);
-                            uint32_t sym, eb, ev;
-                            len_sym((m >> 16) - 3, sym, eb, ev);
-                            atomicAdd(&fl[sym], 1u);
-                            dist_sym(m & 0xffffu, sym, eb, ev);
-                            atomicAdd(&fd[sym], 1u);
-                        }
-                        if (j + adv >= W) misc[M_NEXTPOS] = s - 1 + j + adv;  // unique exit
-                    }
-                    __syncthreads();
-                    if (tid == 0) misc[M_NTOK] = ntok + total;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    const uint32_t t2 = __shfl(J[r], (int)((J[r] - seg_base) & 63u), 64);
+                    J[r + 1] = J[r] < seg_end ? t2 : J[r];
                 }
-                __syncthreads();
-                if (tid == 0) misc[M_CARRY] = marr[CHUNK];  // match of the last position
-                __syncthreads();
+                if (j < W) exitv[j] = (uint16_t)J[6];
+                __syncthreads();  // B: exits of every segment are visible
+                uint32_t pos = entry0;
+                for (int sg = 0; sg < wave; ++sg) {
+                    const uint32_t e = (uint32_t)(sg + 1) << 6;
+                    if (pos < (e < W ? e : W)) pos = exitv[pos];
+                }
+                // lane k follows k hops from the segment entry
+                uint32_t Pk = pos;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    const uint32_t t2 = __shfl(J[r], (int)((Pk - seg_base) & 63u), 64);
+                    if (((lane >> r) & 1) && Pk < seg_end) Pk = t2;
+                }
+                const bool on = Pk < seg_end;  // this lane holds a token of the segment
+                uint32_t kind = 0, m = 0;
+                if (on) {
+                    kind = kindv[Pk];
+                    if (kind) m = marr[Pk + (kind == 2 ? 1 : 0)];
+                }
+                const uint32_t cnt = on ? (kind == 2 ? 2u : 1u) : 0u;
+                uint32_t inc = cnt;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t y = __shfl_up(inc, d, 64);
+                    if (lane >= d) inc += y;
+                }
+                if (lane == 63) wcnt[wave] = inc;
+                if (wave == WG / 64 - 1 && lane == 0) {
+                    // position after the window's last token: entry of the next window
+                    uint32_t fin = pos;
+                    if (fin < W) fin = exitv[fin];
+                    misc[M_TMP] = s - 1 + fin;
+                }
+                __syncthreads();  // C: token counts of every segment are visible
+                uint32_t wbase = ntok0, wtot = 0;
+#pragma unroll
+                for (int w2 = 0; w2 < WG / 64; ++w2) {
+                    const uint32_t c2 = wcnt[w2];
+                    if (w2 < wave) wbase += c2;
+                    wtot += c2;
+                }
+                if (on) {
+                    uint32_t *dst = tokbuf + wbase + inc - cnt;
+                    if (kind != 1) {
+                        const uint32_t b = ring[(s - 1 + Pk) & (RING - 1)];
+                        *dst++ = b;
+                        atomicAdd(&fl[b], 1u);
+                    }
+                    if (kind != 0) {
+                        *dst = 0x80000000u | ((m >> 16) - 3) << 16 | (m & 0xffffu);
+                        uint32_t sym, eb, ev;
+                        len_sym((m >> 16) - 3, sym, eb, ev);
+                        atomicAdd(&fl[sym], 1u);
+                        dist_sym(m & 0xffffu, sym, eb, ev);
+                        atomicAdd(&fd[sym], 1u);
+                    }
+                }
+                if (tid == 0) {
+                    misc[M_NTOK] = ntok0 + wtot;
+                    if (entry0 < W) misc[M_NEXTPOS] = misc[M_TMP];
+                    misc[M_CARRY] = marr[CHUNK];  // match of the last position
+                }
+                __syncthreads();  // D: scratch may be reused
             }
+            PH_END(4);
             if (ck == nchunks - 1) {
                 // ---- epilogue: the last byte can only be a literal ----
                 if (tid == 0 && misc[M_NEXTPOS] == n - 1) {
@@ -745,6 +879,10 @@ zgpu_deflate_kernel(Params P) {
         }
 
         // ---- finish the unit ----
+        PH_FLUSH();
+#ifdef ZGPU_PROFILE
+        for (int i_ = 0; i_ < 8; ++i_) ph_acc[i_] = 0;
+#endif
         if (tid == 0) {
             uint32_t bp = bitpos, cw = carry_word, bwd = base_word;
             bool ovf = misc[M_OVF] != 0;

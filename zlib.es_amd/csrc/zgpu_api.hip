@@ -18,8 +18,10 @@
 namespace {
 
 thread_local int g_last_hip = 0;
-int g_max_chain = 32;
+int g_max_chain = 8;
 int g_nice = 258;
+int g_min_lazy = 258;  // the parse always looks one position ahead unless told otherwise
+unsigned long long *g_prof = nullptr;  // diagnostic builds only
 
 #define HIPCHK(expr)                         \
     do {                                     \
@@ -179,10 +181,31 @@ const char *zgpu_strerror(int code) {
 
 int zgpu_last_hip_error(void) { return g_last_hip; }
 
+#ifdef ZGPU_PROFILE
+// Diagnostic build only (not part of include/zgpu.h): per-phase cycle sums of
+// thread 0 of every workgroup since the last reset.
+int zgpu_prof_read(unsigned long long *out8, int reset) {
+    if (!g_prof) {
+        HIPCHK(hipMalloc(&g_prof, 64));
+        HIPCHK(hipMemset(g_prof, 0, 64));
+    }
+    HIPCHK(hipDeviceSynchronize());
+    if (out8) HIPCHK(hipMemcpy(out8, g_prof, 64, hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(hipMemset(g_prof, 0, 64));
+    return ZGPU_OK;
+}
+#endif
+
 int zgpu_set_search(int max_chain, int nice_length) {
     if (max_chain < 1 || max_chain > 4096 || nice_length < 3 || nice_length > 258) return ZGPU_E_ARG;
     g_max_chain = max_chain;
     g_nice = nice_length;
+    return ZGPU_OK;
+}
+
+int zgpu_set_min_lazy(int min_lazy) {
+    if (min_lazy < 0 || min_lazy > 258) return ZGPU_E_ARG;
+    g_min_lazy = min_lazy;
     return ZGPU_OK;
 }
 
@@ -293,10 +316,11 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
         P.counter = p->d_counter;
         P.n_units = p->n_units;
         P.ctype = p->ctype;
-        P.lazy = p->lazy;
+        P.lazy = p->lazy > g_min_lazy ? p->lazy : g_min_lazy;
         P.max_chain = g_max_chain;
         P.nice = g_nice;
         P.flags = p->flags;
+        P.prof = g_prof;
         hipLaunchKernelGGL(zgpu_deflate_kernel, dim3(p->grid), dim3(1024), 0, st, P);
     }
     HIPCHK(hipGetLastError());
