@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import zlib_es_amd as z  # noqa: E402
 
-PHASES = ["load", "insert", "search", "wait", "parse", "codes+hdr", "emit", "-"]
+PHASES = ["load", "blkwait", "iters", "items", "-", "codes+hdr", "emit", "emit-tok", "lag+ld", "sort", "linkwait", "link", "pass1", "pass2", "prep", "parsewait"]
 
 
 def run(name, data, nu, ub, ctype, lazy):
@@ -25,7 +25,7 @@ def run(name, data, nu, ub, ctype, lazy):
     in_off = np.arange(nu + 1, dtype=np.uint64) * np.uint64(ub)
     plan = z.Plan(in_off, ctype, lazy, 1)
     out = torch.empty(plan.out_bound + 64, dtype=torch.uint8, device="cuda")
-    prof = np.zeros(8, dtype=np.uint64)
+    prof = np.zeros(16, dtype=np.uint64)
     L.zgpu_prof_read(prof.ctypes.data, 1)
     plan.run(data.data_ptr(), out.data_ptr(), out.numel(), None)
     torch.cuda.synchronize()
@@ -37,10 +37,11 @@ def run(name, data, nu, ub, ctype, lazy):
     L.zgpu_prof_read(prof.ctypes.data, 1)
     off, _, _ = plan.fetch()
     nbytes = nu * ub
+    print("  pass1 iterations per item: %.1f ; cycles per iteration: %.0f" % (prof[2] / max(1, prof[3]), prof[12] / max(1, prof[2])))
     per = prof.astype(np.float64) / nbytes
     print("%-8s %7.2f GB/s ratio %.4f | cyc/B: %s | total %.1f" % (
         name, nbytes / dt / 1e9, int(off[-1]) / nbytes,
-        " ".join("%s=%.1f" % (p, v) for p, v in zip(PHASES[:7], per[:7])), per.sum()), flush=True)
+        " ".join("%s=%.1f" % (p, v) for p, v in zip(PHASES, per) if p != "-"), per.sum()), flush=True)
 
 
 def main():

@@ -26,10 +26,10 @@ namespace {
 
 // Optional per-phase cycle counters (diagnostic build only: -DZGPU_PROFILE).
 #ifdef ZGPU_PROFILE
-#define PH_DECL unsigned long long ph_t0 = 0, ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PH_DECL unsigned long long ph_t0 = 0, ph_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PH_START() do { if (tid == 0) ph_t0 = clock64(); } while (0)
 #define PH_END(i) do { if (tid == 0) { unsigned long long t_ = clock64(); ph_acc[i] += t_ - ph_t0; ph_t0 = t_; } } while (0)
-#define PH_FLUSH() do { if (tid == 0 && P.prof) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&P.prof[i_], ph_acc[i_]); } while (0)
+#define PH_FLUSH() do { if (tid == 0 && P.prof) for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&P.prof[i_], ph_acc[i_]); } while (0)
 #else
 #define PH_DECL
 #define PH_START()
@@ -38,13 +38,15 @@ namespace {
 #endif
 
 constexpr int WG = 1024;
-constexpr int CHUNK = 1024;         // positions inserted/searched per step
 constexpr int HBITS = 13;           // hash-head table entries = 1 << HBITS
 constexpr uint32_t RING = 65536;    // LDS input ring (bytes)
 constexpr uint32_t RING_PAD = 272;  // mirror of ring[0..272) after the end
 constexpr uint32_t WMASK = 0x7fff;  // chain slots (32 Ki positions)
-constexpr uint32_t MAXDIST = 32768 - CHUNK;
-constexpr int BLK_CHUNKS = 64;      // one DEFLATE block per 64 KiB of input
+constexpr int PEND = 3;             // searched items a wave may hold before it must parse the oldest
+constexpr uint32_t LAG = 48;        // an item starts only when all items more than LAG back are parsed
+constexpr uint32_t MAXDIST = 32768 - 64 * LAG - 128;  // window minus the span of in-flight items
+constexpr uint32_t BLK_ITEMS = 1024;  // one DEFLATE block per 64 KiB of input
+constexpr uint32_t LOOKAHEAD = 64 + 6 * 64 + 258 + 16;  // bytes an item may read past its start
 constexpr uint32_t REFILL = 16384;  // ring refill granule
 constexpr uint32_t CMP_CAP = 32;   // pass-1 compare length cap (bytes)
 constexpr uint32_t SHARE_MIN = 16;  // matches at least this long offer their distance to the wave
@@ -63,14 +65,14 @@ constexpr uint32_t SCR_BYTES = 14336;
 constexpr uint32_t L_TOTAL = L_SCR + SCR_BYTES;
 static_assert(L_TOTAL <= 163840, "LDS budget");
 
-// scratch, insert phase
-constexpr uint32_t S_SORT = 0;  // u32[1024]
-// scratch, search/parse phase
-constexpr uint32_t S_MARR = 0;                       // u32[CHUNK+2] match per position
-constexpr uint32_t S_JA = S_MARR + (CHUNK + 2) * 4;  // u16[CHUNK+2]
-constexpr uint32_t S_JB = S_JA + (CHUNK + 2) * 2;    // u16[CHUNK+2]
-constexpr uint32_t S_MARK = S_JB + (CHUNK + 2) * 2;  // u8[CHUNK+4]
-static_assert(S_MARK + CHUNK + 4 <= SCR_BYTES, "parse scratch");
+// scratch, item loop (parse bookkeeping of in-flight items)
+constexpr uint32_t NSLOT = 64;                       // > LAG
+constexpr uint32_t S_EXIT = 0;                       // u16[NSLOT*64]
+constexpr uint32_t S_CNT = S_EXIT + NSLOT * 64 * 2;  // u8[NSLOT*64]
+constexpr uint32_t S_DONE = S_CNT + NSLOT * 64;      // u32[NSLOT]
+constexpr uint32_t S_ENT = S_DONE + NSLOT * 4;       // u32[NSLOT]
+constexpr uint32_t S_TOKB = S_ENT + NSLOT * 4;       // u32[NSLOT]
+static_assert(S_TOKB + NSLOT * 4 <= SCR_BYTES, "item-loop scratch");
 // scratch, block close phase
 constexpr uint32_t S_STAGE = 0;                        // u32[STAGE_WORDS]
 constexpr uint32_t S_LLTAB = S_STAGE + STAGE_WORDS * 4;  // u32[288] code | len<<16
@@ -89,8 +91,14 @@ constexpr uint32_t H_NRLE = 5568;    // u32
 static_assert(HUF_BYTES >= 5572, "huffman scratch");
 
 // misc words
-enum { M_SCAN = 0 /*[16]*/, M_WCNT = 16 /*[16]*/, M_UNIT = 32, M_NEXTPOS = 33, M_NTOK = 34, M_TMP = 35, M_OVF = 36,
-       M_CARRY = 37, M_TURN = 38 };
+enum { M_SCAN = 0 /*[16]*/, M_UNIT = 32, M_NTOK = 34, M_TMP = 35, M_OVF = 36,
+       M_ITEM = 40,    // next item to hand out
+       M_LINK = 41,    // item whose turn it is to link its hash chains
+       M_PARSE = 42,   // item whose turn it is to take the parse hand-off
+       M_ENTRY = 43,   // unit position of the next token (belongs to item M_PARSE)
+       M_LOADED = 44,  // input bytes resident in the ring (exclusive end)
+       M_LOCK = 45     // try-lock of the parse frontier
+};
 
 struct Lds {
     uint8_t *base;
@@ -108,6 +116,33 @@ __device__ inline uint32_t ld4u(const uint8_t *ring, uint32_t idx) {
     uint32_t lo = w[0], hi = w[1];
     return __builtin_amdgcn_alignbyte(hi, lo, idx & 3u);
 }
+
+// input bytes [lo, hi) of the unit -> ring (and the mirror of its first bytes);
+// lo is a multiple of 16.  `nthreads` threads with ids `t` cooperate.
+__device__ inline void load_ring(uint8_t *ring, const uint8_t *in, uint32_t lo, uint32_t hi, int t,
+                                 int nthreads, bool aligned) {
+    uint32_t done = lo;
+    if (aligned) {
+        const uint32_t hi16 = lo + ((hi - lo) & ~15u);
+        for (uint32_t p = lo + (uint32_t)t * 16; p < hi16; p += (uint32_t)nthreads * 16) {
+            const uint4 v = *(const uint4 *)(in + p);
+            const uint32_t ri = p & (RING - 1);
+            *(uint4 *)(ring + ri) = v;
+            if (ri < RING_PAD) *(uint4 *)(ring + RING + ri) = v;
+        }
+        done = hi16;
+    }
+    for (uint32_t p = done + (uint32_t)t; p < hi; p += (uint32_t)nthreads) {
+        const uint32_t ri = p & (RING - 1);
+        const uint8_t b = in[p];
+        ring[ri] = b;
+        if (ri < RING_PAD) ring[RING + ri] = b;
+    }
+}
+
+// unaligned dword from LDS in one instruction (gfx950 supports unaligned DS access)
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+__device__ inline uint32_t ld4(const uint8_t *p) { return *(const u32_unaligned *)p; }
 
 __device__ inline uint32_t hash3(uint32_t w) {
     return ((w & 0xffffffu) * 0x9E3779B1u) >> (32 - HBITS);
@@ -166,6 +201,11 @@ __device__ inline void bitonic_sort(uint32_t *a, int n) {
 __device__ inline void lds_wait_eq(uint32_t *word, uint32_t want) {
     volatile uint32_t *w = word;
     while (*w != want) __builtin_amdgcn_s_sleep(0);
+    asm volatile("" ::: "memory");
+}
+__device__ inline void lds_wait_ge(uint32_t *word, uint32_t want) {
+    volatile uint32_t *w = word;
+    while ((int32_t)(*w - want) < 0) __builtin_amdgcn_s_sleep(0);
     asm volatile("" ::: "memory");
 }
 __device__ inline void lds_publish(uint32_t *word, uint32_t value) {
@@ -349,7 +389,7 @@ struct Params {
     uint32_t n_units;
     int ctype, lazy, max_chain, nice;
     uint32_t flags;
-    unsigned long long *prof;  // 8 phase counters (diagnostic builds) or null
+    unsigned long long *prof;  // 16 phase counters (diagnostic builds) or null
 };
 
 }  // namespace
@@ -386,19 +426,29 @@ zgpu_deflate_kernel(Params P) {
         for (int i = tid; i < (1 << HBITS) / 8; i += WG)
             ((uint4 *)head)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
         for (int i = tid; i < 320; i += WG) fl[i] = 0;  // fl[288] + fd[32] are adjacent
-        if (tid == 0) {
-            misc[M_NEXTPOS] = 0;
-            misc[M_NTOK] = 0;
-            misc[M_OVF] = 0;
-            misc[M_CARRY] = 0;
-            misc[M_TURN] = 0;
-        }
         uint32_t bitpos = 0;      // bits emitted so far in this unit (uniform)
         uint32_t base_word = 0;   // output word index of stage[0] (uniform)
         uint32_t carry_word = 0;  // partial word carried between blocks (uniform)
-        const uint32_t nchunks = (n + CHUNK - 1) / CHUNK;
+        const uint32_t nitems = (n + 63) >> 6;  // items of 64 positions
         const bool aligned = (((uintptr_t)in) & 15u) == 0;
+        PH_START();
+        {
+            // first 32 KiB of the unit -> ring (all threads)
+            const uint32_t hi = n < 2 * REFILL ? n : 2 * REFILL;
+            load_ring(ring, in, 0, hi, tid, WG, aligned);
+            if (tid == 0) {
+                misc[M_ITEM] = 0;
+                misc[M_LINK] = 0;
+                misc[M_PARSE] = 0;
+                misc[M_ENTRY] = 0;
+                misc[M_NTOK] = 0;
+                misc[M_OVF] = 0;
+                misc[M_LOADED] = hi;
+                misc[M_LOCK] = 0;
+            }
+        }
         __syncthreads();
+        PH_END(0);
 
         // ---- close a DEFLATE block (all threads; uniform) ----
         auto close_block = [&](const bool last_block) {
@@ -595,293 +645,339 @@ zgpu_deflate_kernel(Params P) {
                 };
 
         if (n == 0) close_block(true);
-        for (uint32_t ck = 0; ck < nchunks; ++ck) {
-            const uint32_t s = ck * CHUNK;
-            PH_START();
-            // ---- load: keep the ring filled to s + 32 KiB ----
-            if ((ck & 15u) == 0) {
-                uint32_t lo = ck == 0 ? 0 : s + REFILL;
-                uint32_t hi = s + 2 * REFILL;
-                if (hi > n) hi = n;
-                if (lo < hi) {
-                    if (aligned) {
-                        uint32_t hi16 = lo + ((hi - lo) & ~15u);
-                        for (uint32_t p = lo + tid * 16; p < hi16; p += WG * 16) {
-                            uint4 v = *(const uint4 *)(in + p);
-                            uint32_t ri = p & (RING - 1);
-                            *(uint4 *)(ring + ri) = v;
-                            if (ri < RING_PAD) *(uint4 *)(ring + RING + ri) = v;
+        for (uint32_t blk_first = 0; blk_first < nitems; blk_first += BLK_ITEMS) {
+            const uint32_t blk_end = blk_first + BLK_ITEMS < nitems ? blk_first + BLK_ITEMS : nitems;
+            // ---- item loop: every wave takes the next 64 positions, no workgroup barrier ----
+            // The parse of an item is deferred until the wave has searched its next item, so
+            // that the in-order parse hand-off rarely has to wait for a slower earlier item.
+            // ---- parse bookkeeping shared by the waves (in the phase scratch) ----
+            // Per in-flight item (slot = item mod NSLOT): for every local index the exit
+            // index and the number of tokens when the parse enters the item there, the
+            // "searched" stamp, and -- once the parse frontier has passed the item -- its
+            // entry position and token base.  Any wave moves the frontier (M_PARSE, M_ENTRY,
+            // M_NTOK) under a try-lock; it never waits for the item's owner.
+            uint16_t *exit_tab = (uint16_t *)(scr + S_EXIT);
+            uint8_t *cnt_tab = scr + S_CNT;
+            uint32_t *slot_done = (uint32_t *)(scr + S_DONE);
+            uint32_t *slot_entry = (uint32_t *)(scr + S_ENT);
+            uint32_t *slot_tokb = (uint32_t *)(scr + S_TOKB);
+            if (tid < (int)NSLOT) slot_done[tid] = 0;  // the scratch held other data during block close
+            __syncthreads();
+            auto try_advance = [&]() {
+                if (lane == 0) {
+                    for (;;) {
+                        if (atomicCAS(&misc[M_LOCK], 0u, 1u) != 0u) break;  // someone else is at it
+                        uint32_t f = misc[M_PARSE], e = misc[M_ENTRY], t = misc[M_NTOK];
+                        while (*(volatile uint32_t *)&slot_done[f & (NSLOT - 1)] == f + 1) {
+                            const uint32_t sl = f & (NSLOT - 1), le = e - (f << 6);
+                            slot_entry[sl] = e;
+                            slot_tokb[sl] = t;
+                            if (le < 64u) {
+                                e = (f << 6) + exit_tab[sl * 64 + le];
+                                t += cnt_tab[sl * 64 + le];
+                            }
+                            ++f;
                         }
-                        for (uint32_t p = hi16 + tid; p < hi; p += WG) {
-                            uint32_t ri = p & (RING - 1);
-                            uint8_t b = in[p];
-                            ring[ri] = b;
-                            if (ri < RING_PAD) ring[RING + ri] = b;
-                        }
+                        misc[M_ENTRY] = e;
+                        misc[M_NTOK] = t;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        *(volatile uint32_t *)&misc[M_PARSE] = f;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        *(volatile uint32_t *)&misc[M_LOCK] = 0u;
+                        // an item stamped while the lock was held must not be left behind
+                        if (*(volatile uint32_t *)&slot_done[f & (NSLOT - 1)] != f + 1) break;
+                    }
+                }
+            };
+            // Up to PEND searched items wait per wave until the frontier has passed them
+            // (slot 0 is the oldest); then their tokens are emitted.
+            int npend = 0;
+            uint32_t q_k[PEND], q_len[PEND], q_dist[PEND];
+            // kind / successor of every local index of an item (0 literal, 1 match here,
+            // 2 literal + match at +1); no look-ahead across the item boundary
+            auto successor = [&](uint32_t best_len, uint32_t &kind) -> uint32_t {
+                uint32_t l1 = __shfl_down(best_len, 1, 64);
+                if (lane == 63) l1 = 0;
+                uint32_t adv = 1;
+                kind = 0;
+                if (best_len >= 3) {
+                    if (P.lazy > 0 && best_len < (uint32_t)P.lazy && l1 > best_len) {
+                        kind = 2;
+                        adv = 1 + l1;
                     } else {
-                        for (uint32_t p = lo + tid; p < hi; p += WG) {
-                            uint32_t ri = p & (RING - 1);
-                            uint8_t b = in[p];
-                            ring[ri] = b;
-                            if (ri < RING_PAD) ring[RING + ri] = b;
-                        }
+                        kind = 1;
+                        adv = best_len;
                     }
                 }
-                __syncthreads();
-            }
-            PH_END(0);
-            {
-                // ---- insert: per-wave sort of (hash, lane), chains linked wave after wave ----
-                // Wave w owns positions [s+64w, s+64w+64).  Its lanes sort their
-                // (hash<<6 | lane) keys in registers; equal hashes become adjacent, which
-                // gives every element its predecessor inside the wave.  The first element
-                // of each hash run links to head[hash]; the last one becomes the new head.
-                // Waves take turns in position order (a ticket in LDS), so head[] always
-                // holds the latest earlier position when a wave reads it.
-                const uint32_t p = s + tid;
-                uint32_t key = 0xffffffffu;
-                if (p + 3 <= n) key = (hash3(ld4u(ring, p & (RING - 1))) << 6) | (uint32_t)lane;
-                key = wave_sort64(key);
-                const uint32_t kp = __shfl_up(key, 1, 64), kn = __shfl_down(key, 1, 64);
-                const uint32_t h = key >> 6;
-                const bool live = key != 0xffffffffu;
-                const bool first = lane == 0 || (kp >> 6) != h;
-                const bool last = lane == 63 || (kn >> 6) != h || kn == 0xffffffffu;
-                const uint32_t mypos = s + (uint32_t)(wave << 6) + (key & 63u);
-                const uint32_t ticket = ck * (WG / 64) + (uint32_t)wave;
-                lds_wait_eq(&misc[M_TURN], ticket);
-                if (live) {
-                    const uint32_t pp = first ? (uint32_t)head[h]
-                                              : (s + (uint32_t)(wave << 6) + (kp & 63u));
-                    prevt[mypos & WMASK] = (uint16_t)pp;
+                return (uint32_t)lane + adv;
+            };
+            auto resolved = [&](uint32_t k0) -> bool {
+                return (int32_t)(*(volatile uint32_t *)&misc[M_PARSE] - k0) > 0;
+            };
+            auto emit_oldest = [&]() {
+                // ---- tokens of item q_k[0], in registers: lane l <-> local index l ----
+                // five pointer-doubling steps rebuild the jump tables; lane j then follows j
+                // hops from the entry by composing the tables along the bits of j, so the
+                // tokens come out already compacted.
+                const uint32_t k0 = q_k[0], best_len = q_len[0], best_dist = q_dist[0];
+                const uint32_t p0 = k0 << 6, sl = k0 & (NSLOT - 1);
+                const uint32_t seg_end = (n - p0) < 64u ? (n - p0) : 64u;
+                PH_START();
+                while (!resolved(k0)) {
+                    try_advance();
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                if (live && last) head[h] = (uint16_t)mypos;
-                lds_publish(&misc[M_TURN], ticket + 1);
-                PH_END(1);
-            }
-            {
-                // ---- search: one lane per position (candidates lie in this or earlier waves) ----
-                uint32_t *marr = (uint32_t *)(scr + S_MARR);
-                const uint32_t p = s + tid;
-                uint32_t best_len = 0, best_dist = 0;
-                const uint32_t maxlen = p < n ? ((n - p) < 258u ? (n - p) : 258u) : 0u;
-                uint32_t blen = 2;
-                if (p + 3 <= n) {
-                    // pass 1, lane per position: walk the hash chain; compares stop at
-                    // CMP_CAP bytes so that every lane's work is bounded
-                    const uint32_t pi = p & (RING - 1);
-                    const uint32_t cmpmax = maxlen < CMP_CAP ? maxlen : CMP_CAP;
-                    const uint32_t stop = cmpmax < (uint32_t)P.nice ? cmpmax : (uint32_t)P.nice;
-                    const uint32_t limit = p < MAXDIST ? p : MAXDIST;
-                    const uint32_t pw0 = ld4u(ring, pi);
-                    uint32_t c = prevt[p & WMASK];
-                    uint32_t last = 0;
-                    for (int budget = P.max_chain; budget > 0; --budget) {
-                        const uint32_t dist = (p - c) & 0xffffu;
-                        if (dist <= last || dist > limit) break;
-                        last = dist;
-                        const uint32_t ci = c & (RING - 1);
-                        const uint32_t x0 = ld4u(ring, ci) ^ pw0;
-                        if ((x0 & 0xffffffu) == 0 &&
-                            (blen < 3 || ring[ci + blen] == ring[pi + blen])) {
-                            uint32_t len;
-                            if (x0)
-                                len = 3;
-                            else {
-                                len = 4;
-                                while (len < cmpmax) {
-                                    uint32_t x = ld4u(ring, ci + len) ^ ld4u(ring, pi + len);
-                                    if (x) {
-                                        len += (uint32_t)__builtin_ctz(x) >> 3;
-                                        break;
-                                    }
-                                    len += 4;
-                                }
-                            }
-                            if (len > cmpmax) len = cmpmax;
-                            if (len > blen) {
-                                blen = len;
-                                best_dist = dist;
-                                if (len >= stop) break;
-                            }
-                        }
-                        c = prevt[c & WMASK];
-                    }
+                asm volatile("" ::: "memory");
+                PH_END(15);
+                const uint32_t e = slot_entry[sl] - p0;  // local index of the first token
+                const uint32_t tokbase = slot_tokb[sl];
+                uint32_t kind;
+                uint32_t QJ[6];
+                QJ[0] = successor(best_len, kind);
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    const uint32_t tj = __shfl(QJ[r], (int)(QJ[r] & 63u), 64);
+                    QJ[r + 1] = QJ[r] < seg_end ? tj : QJ[r];
                 }
-                {
-                    // pass 2, distance sharing across the wave: a distance that gave one
-                    // lane a long match is scored for all 64 positions at once -- one byte
-                    // compare per lane, a ballot, and count-trailing-ones give every lane
-                    // its exact match length (up to 258) at that distance.
-                    const uint32_t p0 = s + ((uint32_t)wave << 6);
-                    const uint32_t offer = best_dist;
-                    unsigned long long todo = __ballot(blen >= SHARE_MIN);
-                    for (int it = 0; it < SHARE_ITERS && todo; ++it) {
-                        const int src = __builtin_ctzll(todo);
-                        const uint32_t d = (uint32_t)__shfl((int)offer, src, 64);
-                        uint32_t run = 0;
-                        bool open = true;
-                        for (uint32_t w = 0; w < 6; ++w) {
-                            const uint32_t q = p0 + (w << 6) + (uint32_t)lane;
-                            const bool eq = q < n && q >= d &&
-                                            ring[q & (RING - 1)] == ring[(q - d) & (RING - 1)];
-                            const unsigned long long m = __ballot(eq);
-                            if (w == 0) {
-                                const unsigned long long inv = ~(m >> lane);
-                                // ones shifted in above bit 63-lane read as mismatches after the inversion
-                                run = inv ? (uint32_t)__builtin_ctzll(inv) : 64u;
-                                if (run > 64u - (uint32_t)lane) run = 64u - (uint32_t)lane;
-                                open = run == 64u - (uint32_t)lane;
-                            } else if (open) {
-                                const uint32_t r2 = ~m ? (uint32_t)__builtin_ctzll(~m) : 64u;
-                                run += r2;
-                                open = r2 == 64u;
-                            }
-                            if (!__ballot(open && run < 258u)) break;
-                        }
-                        if (run > maxlen) run = maxlen;
-                        if (run >= 3 && d <= (p < MAXDIST ? p : MAXDIST) &&
-                            (run > blen || (run == blen && d < best_dist))) {
-                            blen = run;
-                            best_dist = d;
-                        }
-                        todo &= ~__ballot(offer == d);
-                    }
-                }
-                if (blen >= 3 && !(blen == 3 && best_dist > 4096)) best_len = blen;
-                marr[1 + tid] = (best_len << 16) | (best_len ? best_dist - 1 : 0);
-                if (tid == 0) marr[0] = misc[M_CARRY];  // match of position s-1
-                PH_END(2);
-                __syncthreads();  // A: every match of this chunk is in marr
-                PH_END(3);
-            }
-            {
-                // ---- parse window [s-1, s-1+W): window index j <-> position s-1+j ----
-                // Wave w resolves indices [64w, 64w+64) in registers: successor per index,
-                // six pointer-doubling steps by lane shuffles give the exit of every index,
-                // the entry of each segment follows by walking the exits of the earlier
-                // segments, and the k-th token of a segment is found by composing the
-                // doubling tables along the bits of k (tokens come out already compacted).
-                uint32_t *marr = (uint32_t *)(scr + S_MARR);
-                uint16_t *exitv = (uint16_t *)(scr + S_JA);
-                uint8_t *kindv = scr + S_MARK;
-                uint32_t *wcnt = misc + M_WCNT;
-                const uint32_t W = (n - s) < (uint32_t)CHUNK ? (n - s) : (uint32_t)CHUNK;
-                const uint32_t entry0 = misc[M_NEXTPOS] + 1 - s;  // window index of the next token
-                const uint32_t ntok0 = misc[M_NTOK];
-                const uint32_t seg_base = (uint32_t)wave << 6;
-                const uint32_t seg_end = seg_base + 64 < W ? seg_base + 64 : W;
-                const uint32_t j = tid;
-                uint32_t J[7];
-                {
-                    uint32_t kind = 0, adv = 1;  // 0 literal, 1 match here, 2 literal + match at +1
-                    if (j < W) {
-                        const uint32_t m0 = marr[j], m1 = marr[j + 1];
-                        uint32_t l0 = m0 >> 16;
-                        const uint32_t l1 = m1 >> 16;
-                        if (j == 0 && s == 0) l0 = 0;
-                        if (l0 >= 3) {
-                            if (P.lazy > 0 && l0 < (uint32_t)P.lazy && l1 > l0) {
-                                kind = 2;
-                                adv = 1 + l1;
-                            } else {
-                                kind = 1;
-                                adv = l0;
-                            }
-                        }
-                        kindv[j] = (uint8_t)kind;
-                    }
-                    J[0] = j + adv;
-                }
+                uint32_t Pk = e;
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
-                    const uint32_t t2 = __shfl(J[r], (int)((J[r] - seg_base) & 63u), 64);
-                    J[r + 1] = J[r] < seg_end ? t2 : J[r];
-                }
-                if (j < W) exitv[j] = (uint16_t)J[6];
-                __syncthreads();  // B: exits of every segment are visible
-                uint32_t pos = entry0;
-                for (int sg = 0; sg < wave; ++sg) {
-                    const uint32_t e = (uint32_t)(sg + 1) << 6;
-                    if (pos < (e < W ? e : W)) pos = exitv[pos];
-                }
-                // lane k follows k hops from the segment entry
-                uint32_t Pk = pos;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    const uint32_t t2 = __shfl(J[r], (int)((Pk - seg_base) & 63u), 64);
+                    const uint32_t t2 = __shfl(QJ[r], (int)(Pk & 63u), 64);
                     if (((lane >> r) & 1) && Pk < seg_end) Pk = t2;
                 }
-                const bool on = Pk < seg_end;  // this lane holds a token of the segment
-                uint32_t kind = 0, m = 0;
-                if (on) {
-                    kind = kindv[Pk];
-                    if (kind) m = marr[Pk + (kind == 2 ? 1 : 0)];
-                }
-                const uint32_t cnt = on ? (kind == 2 ? 2u : 1u) : 0u;
+                const bool on = Pk < seg_end;
+                const uint32_t tk = (uint32_t)__shfl((int)kind, (int)(Pk & 63u), 64);
+                const int mi = (int)((Pk + (tk == 2 ? 1u : 0u)) & 63u);
+                const uint32_t tl = (uint32_t)__shfl((int)best_len, mi, 64);
+                const uint32_t td = (uint32_t)__shfl((int)best_dist, mi, 64);
+                const uint32_t cnt = on ? (tk == 2 ? 2u : 1u) : 0u;
                 uint32_t inc = cnt;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) {
                     const uint32_t y = __shfl_up(inc, d, 64);
                     if (lane >= d) inc += y;
                 }
-                if (lane == 63) wcnt[wave] = inc;
-                if (wave == WG / 64 - 1 && lane == 0) {
-                    // position after the window's last token: entry of the next window
-                    uint32_t fin = pos;
-                    if (fin < W) fin = exitv[fin];
-                    misc[M_TMP] = s - 1 + fin;
-                }
-                __syncthreads();  // C: token counts of every segment are visible
-                uint32_t wbase = ntok0, wtot = 0;
-#pragma unroll
-                for (int w2 = 0; w2 < WG / 64; ++w2) {
-                    const uint32_t c2 = wcnt[w2];
-                    if (w2 < wave) wbase += c2;
-                    wtot += c2;
-                }
                 if (on) {
-                    uint32_t *dst = tokbuf + wbase + inc - cnt;
-                    if (kind != 1) {
-                        const uint32_t b = ring[(s - 1 + Pk) & (RING - 1)];
+                    uint32_t *dst = tokbuf + tokbase + inc - cnt;
+                    if (tk != 1) {
+                        const uint32_t b = ring[(p0 + Pk) & (RING - 1)];
                         *dst++ = b;
                         atomicAdd(&fl[b], 1u);
                     }
-                    if (kind != 0) {
-                        *dst = 0x80000000u | ((m >> 16) - 3) << 16 | (m & 0xffffu);
+                    if (tk != 0) {
+                        *dst = 0x80000000u | (tl - 3) << 16 | (td - 1);
                         uint32_t sym, eb, ev;
-                        len_sym((m >> 16) - 3, sym, eb, ev);
+                        len_sym(tl - 3, sym, eb, ev);
                         atomicAdd(&fl[sym], 1u);
-                        dist_sym(m & 0xffffu, sym, eb, ev);
+                        dist_sym(td - 1, sym, eb, ev);
                         atomicAdd(&fd[sym], 1u);
                     }
                 }
-                if (tid == 0) {
-                    misc[M_NTOK] = ntok0 + wtot;
-                    if (entry0 < W) misc[M_NEXTPOS] = misc[M_TMP];
-                    misc[M_CARRY] = marr[CHUNK];  // match of the last position
+#pragma unroll
+                for (int i = 0; i + 1 < PEND; ++i) {
+                    q_k[i] = q_k[i + 1];
+                    q_len[i] = q_len[i + 1];
+                    q_dist[i] = q_dist[i + 1];
                 }
-                __syncthreads();  // D: scratch may be reused
-            }
-            PH_END(4);
-            if (ck == nchunks - 1) {
-                // ---- epilogue: the last byte can only be a literal ----
-                if (tid == 0 && misc[M_NEXTPOS] == n - 1) {
-                    uint32_t b = ring[(n - 1) & (RING - 1)];
-                    tokbuf[misc[M_NTOK]++] = b;
-                    fl[b]++;
-                    misc[M_NEXTPOS] = n;
+                --npend;
+                PH_END(7);
+            };
+            for (;;) {
+                uint32_t k = 0;
+                if (lane == 0) k = atomicAdd(&misc[M_ITEM], 1u);
+                k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+                if (k >= blk_end) break;
+                PH_START();
+                const uint32_t p0 = k << 6;
+                const uint32_t p = p0 + (uint32_t)lane;
+                // An unparsed item more than LAG items back must be parsed first, or the
+                // waves that wait for it below could never be released.
+                while (npend > 0 && k > q_k[0] + LAG) emit_oldest();
+                // bound the spread of in-flight items: everything more than LAG items back is
+                // parsed, so no wave still reads ring bytes or chain slots that get recycled
+                if (k > LAG) lds_wait_ge(&misc[M_PARSE], k - LAG);
+                // ring refill every 16 KiB, by the wave that crosses the boundary
+                if (k && (p0 & (REFILL - 1)) == 0) {
+                    uint32_t lo = p0 + REFILL, hi = p0 + 2 * REFILL;
+                    if (hi > n) hi = n;
+                    if (lo < hi) {
+                        load_ring(ring, in, lo, hi, lane, 64, aligned);
+                        lds_publish(&misc[M_LOADED], hi);
+                    }
                 }
-                __syncthreads();
+                {
+                    uint32_t need = p0 + LOOKAHEAD;
+                    if (need > n) need = n;
+                    lds_wait_ge(&misc[M_LOADED], need);
+                }
+#ifdef ZGPU_PROFILE
+                if (tid == 0) ph_acc[3]++;
+#endif
+                PH_END(8);
+                // ---- insert: sort (hash, lane) in registers, link chains in item order ----
+                uint32_t key = 0xffffffffu;
+                if (p + 3 <= n) key = (hash3(ld4(ring + (p & (RING - 1)))) << 6) | (uint32_t)lane;
+                key = wave_sort64(key);
+                {
+                    const uint32_t kp = __shfl_up(key, 1, 64), kn = __shfl_down(key, 1, 64);
+                    const uint32_t h = key >> 6;
+                    const bool live = key != 0xffffffffu;
+                    const bool first = lane == 0 || (kp >> 6) != h;
+                    const bool last = lane == 63 || (kn >> 6) != h || kn == 0xffffffffu;
+                    const uint32_t mypos = p0 + (key & 63u);
+                    PH_END(9);
+                    lds_wait_eq(&misc[M_LINK], k);
+                    PH_END(10);
+                    if (live) {
+                        const uint32_t pp = first ? (uint32_t)head[h] : (p0 + (kp & 63u));
+                        prevt[mypos & WMASK] = (uint16_t)pp;
+                    }
+                    if (live && last) head[h] = (uint16_t)mypos;
+                    lds_publish(&misc[M_LINK], k + 1);
+                }
+                PH_END(11);
+                // ---- search ----
+                uint32_t best_len = 0, best_dist = 0;
+                {
+                    const uint32_t maxlen = p < n ? ((n - p) < 258u ? (n - p) : 258u) : 0u;
+                    const uint32_t limit = p < MAXDIST ? p : MAXDIST;
+                    uint32_t blen = 2;
+                    {
+                        // pass 1, lane per position: walk the hash chain.  The LDS pipe is the
+                        // scarce resource (random addresses conflict on banks), so a candidate
+                        // costs two LDS reads: its chain link and ONE unaligned dword -- the four
+                        // bytes ending at the current best length (the first four while nothing
+                        // is in hand).  Only a candidate that passes this test is compared from
+                        // the start, four bytes a step, up to CMP_CAP bytes (pass 2 finds the
+                        // exact length of long matches).
+                        const uint32_t pi = p & (RING - 1);
+                        const uint32_t cmpmax = maxlen < CMP_CAP ? maxlen : CMP_CAP;
+                        const uint32_t stop = cmpmax < (uint32_t)P.nice ? cmpmax : (uint32_t)P.nice;
+                        if (p + 3 <= n) {
+                            uint32_t c = prevt[p & WMASK];
+                            uint32_t toff = 0;                 // offset of the test dword
+                            uint32_t ptail = ld4(ring + pi);   // this position's bytes at toff
+                            uint32_t last = 0;
+                            for (int budget = P.max_chain; budget > 0; --budget) {
+                                const uint32_t dist = (p - c) & 0xffffu;
+                                if (dist <= last || dist > limit) break;
+                                last = dist;
+                                const uint32_t ci = c & (RING - 1);
+                                const uint32_t nxt = prevt[c & WMASK];
+                                const uint32_t x = ld4(ring + ci + toff) ^ ptail;
+                                if (blen < 3 ? (x & 0xffffffu) == 0 : x == 0) {
+                                    uint32_t len = 0;
+                                    if (toff == 0) len = x ? 3u : 4u;
+                                    if (!(toff == 0 && x))
+                                        while (len < cmpmax) {
+                                            const uint32_t x2 = ld4(ring + ci + len) ^ ld4(ring + pi + len);
+                                            if (x2) {
+                                                len += (uint32_t)__builtin_ctz(x2) >> 3;
+                                                break;
+                                            }
+                                            len += 4;
+                                        }
+                                    if (len > cmpmax) len = cmpmax;
+                                    if (len > blen) {
+                                        blen = len;
+                                        best_dist = dist;
+                                        if (len >= stop) break;
+                                        toff = len - 3;  // next test: bytes len-3 .. len
+                                        ptail = ld4(ring + pi + toff);
+                                    }
+                                }
+                                c = nxt;
+                            }
+                        }
+                    }
+                    PH_END(12);
+                    {
+                        // pass 2, distance sharing across the wave: a distance that gave one
+                        // lane a long match is scored for all 64 positions at once -- one byte
+                        // compare per lane, a ballot, and count-trailing-ones give every lane
+                        // its exact match length (up to 258) at that distance.
+                        const uint32_t offer = best_dist;
+                        unsigned long long todo = __ballot(blen >= SHARE_MIN);
+                        for (int it = 0; it < SHARE_ITERS && todo; ++it) {
+                            const int src = __builtin_ctzll(todo);
+                            const uint32_t d = (uint32_t)__shfl((int)offer, src, 64);
+                            uint32_t run = 0;
+                            bool open = true;
+                            for (uint32_t w = 0; w < 6; ++w) {
+                                const uint32_t q = p0 + (w << 6) + (uint32_t)lane;
+                                const bool eq = q < n && q >= d &&
+                                                ring[q & (RING - 1)] == ring[(q - d) & (RING - 1)];
+                                const unsigned long long m = __ballot(eq);
+                                if (w == 0) {
+                                    // zeros shifted in from the top read as mismatches after the inversion
+                                    const unsigned long long inv = ~(m >> lane);
+                                    run = inv ? (uint32_t)__builtin_ctzll(inv) : 64u;
+                                    open = run == 64u - (uint32_t)lane;
+                                } else if (open) {
+                                    const uint32_t r2 = ~m ? (uint32_t)__builtin_ctzll(~m) : 64u;
+                                    run += r2;
+                                    open = r2 == 64u;
+                                }
+                                if (!__ballot(open && run < 258u)) break;
+                            }
+                            if (run > maxlen) run = maxlen;
+                            if (run >= 3 && d <= limit && (run > blen || (run == blen && d < best_dist))) {
+                                blen = run;
+                                best_dist = d;
+                            }
+                            todo &= ~__ballot(offer == d);
+                        }
+                    }
+                    if (blen >= 3 && !(blen == 3 && best_dist > 4096)) best_len = blen;
+                }
+                PH_END(13);
+                PH_START();
+                {
+                    // ---- exit index and token count of every local index (six doubling steps) ----
+                    const uint32_t seg_end = (n - p0) < 64u ? (n - p0) : 64u;
+                    uint32_t kind;
+                    uint32_t J = successor(best_len, kind);
+                    if ((uint32_t)lane >= seg_end) J = (uint32_t)lane;  // past the end: stay put
+                    uint32_t Cn = (uint32_t)lane < seg_end ? (kind == 2 ? 2u : 1u) : 0u;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+                        const int idx = (int)(J & 63u);
+                        const uint32_t tj = __shfl(J, idx, 64), tc = __shfl(Cn, idx, 64);
+                        const bool inb = J < seg_end;
+                        Cn += inb ? tc : 0u;
+                        J = inb ? tj : J;
+                    }
+                    const uint32_t sl = k & (NSLOT - 1);
+                    exit_tab[sl * 64 + lane] = (uint16_t)J;
+                    cnt_tab[sl * 64 + lane] = (uint8_t)Cn;
+                }
+                PH_END(14);
+                // tokens of items the frontier has passed leave before this item is stamped:
+                // until then the frontier cannot run far enough to recycle their slots
+                while (npend > 0 && (npend == PEND || resolved(q_k[0]))) emit_oldest();
+#pragma unroll
+                for (int i = 0; i < PEND; ++i)
+                    if (i == npend) {
+                        q_k[i] = k;
+                        q_len[i] = best_len;
+                        q_dist[i] = best_dist;
+                    }
+                ++npend;
+                lds_publish(&slot_done[k & (NSLOT - 1)], k + 1);
+                try_advance();
             }
-            if ((ck % BLK_CHUNKS) != BLK_CHUNKS - 1 && ck != nchunks - 1) continue;
-            close_block(ck == nchunks - 1);
+            while (npend > 0) emit_oldest();
+            PH_START();
+            __syncthreads();
+            PH_END(1);
+            if (tid == 0) misc[M_ITEM] = blk_end;  // the counter overshoots by one per wave
+            close_block(blk_end == nitems);
         }
 
         // ---- finish the unit ----
         PH_FLUSH();
 #ifdef ZGPU_PROFILE
-        for (int i_ = 0; i_ < 8; ++i_) ph_acc[i_] = 0;
+        for (int i_ = 0; i_ < 16; ++i_) ph_acc[i_] = 0;
 #endif
         if (tid == 0) {
             uint32_t bp = bitpos, cw = carry_word, bwd = base_word;

@@ -186,12 +186,12 @@ int zgpu_last_hip_error(void) { return g_last_hip; }
 // thread 0 of every workgroup since the last reset.
 int zgpu_prof_read(unsigned long long *out8, int reset) {
     if (!g_prof) {
-        HIPCHK(hipMalloc(&g_prof, 64));
-        HIPCHK(hipMemset(g_prof, 0, 64));
+        HIPCHK(hipMalloc(&g_prof, 128));
+        HIPCHK(hipMemset(g_prof, 0, 128));
     }
     HIPCHK(hipDeviceSynchronize());
-    if (out8) HIPCHK(hipMemcpy(out8, g_prof, 64, hipMemcpyDeviceToHost));
-    if (reset) HIPCHK(hipMemset(g_prof, 0, 64));
+    if (out8) HIPCHK(hipMemcpy(out8, g_prof, 128, hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(hipMemset(g_prof, 0, 128));
     return ZGPU_OK;
 }
 #endif
