@@ -1,0 +1,276 @@
+// Node.js N-API addon: binds the C ABI of libzgpu.so (include/zgpu.h) for the
+// JavaScript shim in zlib_gpu.js.  N-API version <= 6 (builds against the
+// Node 12 headers).  The addon holds no compression logic: it marshals typed
+// arrays to zgpu_deflate_batch / zgpu_checksum and back.  libzgpu.so is loaded
+// with dlopen at init(), so a missing library or GPU surfaces as a thrown
+// Error, never as a silent fallback.
+#include <dlfcn.h>
+#include <node_api.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+namespace {
+
+typedef int (*fn_deflate_batch)(const uint8_t *, const uint64_t *, uint32_t, int, int, uint32_t, uint8_t *,
+                                uint64_t, uint64_t *, uint32_t *, uint32_t *);
+typedef int (*fn_checksum)(const uint8_t *, uint64_t, uint32_t *, uint32_t *);
+typedef uint64_t (*fn_bound)(uint64_t);
+typedef uint32_t (*fn_combine)(uint32_t, uint32_t, uint64_t);
+typedef const char *(*fn_strerror)(int);
+typedef int (*fn_set2)(int, int);
+typedef int (*fn_set1)(int);
+
+struct Lib {
+    void *h = nullptr;
+    fn_deflate_batch deflate_batch = nullptr;
+    fn_checksum checksum = nullptr;
+    fn_bound bound = nullptr;
+    fn_combine crc_combine = nullptr, adler_combine = nullptr;
+    fn_strerror strerror_ = nullptr;
+    fn_set2 set_search = nullptr;
+    fn_set1 set_min_lazy = nullptr;
+} g;
+
+#define NAPI_OK(call)                                            \
+    do {                                                         \
+        if ((call) != napi_ok) {                                 \
+            napi_throw_error(env, nullptr, "N-API call failed: " #call); \
+            return nullptr;                                      \
+        }                                                        \
+    } while (0)
+
+napi_value throw_zgpu(napi_env env, const char *what, int rc) {
+    std::string msg = std::string(what) + ": " + (g.strerror_ ? g.strerror_(rc) : "libzgpu error") +
+                      " (code " + std::to_string(rc) + ")";
+    napi_throw_error(env, nullptr, msg.c_str());
+    return nullptr;
+}
+
+bool need_lib(napi_env env) {
+    if (g.h) return true;
+    napi_throw_error(env, nullptr, "libzgpu.so is not loaded: call init(path) first (there is no CPU fallback)");
+    return false;
+}
+
+// init(pathToLibzgpu)
+napi_value Init_(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    char path[4096];
+    size_t len = 0;
+    NAPI_OK(napi_get_value_string_utf8(env, argv[0], path, sizeof path, &len));
+    if (g.h) return nullptr;
+    void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+        napi_throw_error(env, nullptr, (std::string("cannot load ") + path + ": " + dlerror()).c_str());
+        return nullptr;
+    }
+    g.deflate_batch = (fn_deflate_batch)dlsym(h, "zgpu_deflate_batch");
+    g.checksum = (fn_checksum)dlsym(h, "zgpu_checksum");
+    g.bound = (fn_bound)dlsym(h, "zgpu_deflate_bound");
+    g.crc_combine = (fn_combine)dlsym(h, "zgpu_crc32_combine");
+    g.adler_combine = (fn_combine)dlsym(h, "zgpu_adler32_combine");
+    g.strerror_ = (fn_strerror)dlsym(h, "zgpu_strerror");
+    g.set_search = (fn_set2)dlsym(h, "zgpu_set_search");
+    g.set_min_lazy = (fn_set1)dlsym(h, "zgpu_set_min_lazy");
+    if (!g.deflate_batch || !g.checksum || !g.bound || !g.crc_combine || !g.adler_combine || !g.strerror_ ||
+        !g.set_search || !g.set_min_lazy) {
+        dlclose(h);
+        napi_throw_error(env, nullptr, "libzgpu.so lacks an expected symbol");
+        return nullptr;
+    }
+    g.h = h;
+    return nullptr;
+}
+
+bool get_u8(napi_env env, napi_value v, const uint8_t **data, size_t *len) {
+    bool is_ta = false;
+    if (napi_is_typedarray(env, v, &is_ta) != napi_ok || !is_ta) return false;
+    napi_typedarray_type t;
+    void *p = nullptr;
+    napi_value ab;
+    size_t off = 0;
+    if (napi_get_typedarray_info(env, v, &t, len, &p, &ab, &off) != napi_ok) return false;
+    if (t != napi_uint8_array && t != napi_uint8_clamped_array && t != napi_int8_array) return false;
+    *data = (const uint8_t *)p;
+    return true;
+}
+
+// deflateBatch(inputs: Uint8Array[], ctype, lazy, flags, wantCrc, wantAdler)
+//   -> { outputs: Uint8Array[] (views into one ArrayBuffer), crc32: Uint32Array|null, adler32: Uint32Array|null }
+napi_value DeflateBatch(napi_env env, napi_callback_info info) {
+    if (!need_lib(env)) return nullptr;
+    size_t argc = 6;
+    napi_value argv[6];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    if (argc < 6) {
+        napi_throw_type_error(env, nullptr, "deflateBatch(inputs, ctype, lazy, flags, wantCrc, wantAdler)");
+        return nullptr;
+    }
+    uint32_t n = 0;
+    NAPI_OK(napi_get_array_length(env, argv[0], &n));
+    int32_t ctype = 0, lazy = 0;
+    uint32_t flags = 0;
+    bool want_crc = false, want_adler = false;
+    NAPI_OK(napi_get_value_int32(env, argv[1], &ctype));
+    NAPI_OK(napi_get_value_int32(env, argv[2], &lazy));
+    NAPI_OK(napi_get_value_uint32(env, argv[3], &flags));
+    NAPI_OK(napi_get_value_bool(env, argv[4], &want_crc));
+    NAPI_OK(napi_get_value_bool(env, argv[5], &want_adler));
+    napi_value result;
+    NAPI_OK(napi_create_object(env, &result));
+    napi_value outs;
+    NAPI_OK(napi_create_array_with_length(env, n, &outs));
+    napi_value null_v;
+    NAPI_OK(napi_get_null(env, &null_v));
+    napi_value crc_v = null_v, adler_v = null_v;
+    if (n) {
+        std::vector<uint64_t> in_off(n + 1, 0), out_off(n + 1, 0);
+        std::vector<const uint8_t *> ptrs(n);
+        uint64_t cap = 64;
+        for (uint32_t i = 0; i < n; ++i) {
+            napi_value e;
+            NAPI_OK(napi_get_element(env, argv[0], i, &e));
+            size_t len = 0;
+            if (!get_u8(env, e, &ptrs[i], &len)) {
+                napi_throw_type_error(env, nullptr, "inputs must be Uint8Array");
+                return nullptr;
+            }
+            in_off[i + 1] = in_off[i] + len;
+            cap += g.bound(len) + 48;
+        }
+        std::vector<uint8_t> flat(in_off[n] ? in_off[n] : 1);
+        for (uint32_t i = 0; i < n; ++i)
+            if (in_off[i + 1] > in_off[i]) memcpy(flat.data() + in_off[i], ptrs[i], in_off[i + 1] - in_off[i]);
+        std::vector<uint8_t> out(cap);
+        std::vector<uint32_t> crc(want_crc ? n : 0), adler(want_adler ? n : 0);
+        int rc = g.deflate_batch(flat.data(), in_off.data(), n, ctype, lazy, flags, out.data(), cap, out_off.data(),
+                                 want_crc ? crc.data() : nullptr, want_adler ? adler.data() : nullptr);
+        if (rc) return throw_zgpu(env, "zgpu_deflate_batch", rc);
+        void *ab_data = nullptr;
+        napi_value ab;
+        NAPI_OK(napi_create_arraybuffer(env, out_off[n], &ab_data, &ab));
+        if (out_off[n]) memcpy(ab_data, out.data(), out_off[n]);
+        for (uint32_t i = 0; i < n; ++i) {
+            napi_value ta;
+            NAPI_OK(napi_create_typedarray(env, napi_uint8_array, out_off[i + 1] - out_off[i], ab, out_off[i], &ta));
+            NAPI_OK(napi_set_element(env, outs, i, ta));
+        }
+        auto make_u32 = [&](const std::vector<uint32_t> &v, napi_value *dst) -> bool {
+            void *d = nullptr;
+            napi_value b;
+            if (napi_create_arraybuffer(env, v.size() * 4, &d, &b) != napi_ok) return false;
+            memcpy(d, v.data(), v.size() * 4);
+            return napi_create_typedarray(env, napi_uint32_array, v.size(), b, 0, dst) == napi_ok;
+        };
+        if (want_crc && !make_u32(crc, &crc_v)) return nullptr;
+        if (want_adler && !make_u32(adler, &adler_v)) return nullptr;
+    }
+    NAPI_OK(napi_set_named_property(env, result, "outputs", outs));
+    NAPI_OK(napi_set_named_property(env, result, "crc32", crc_v));
+    NAPI_OK(napi_set_named_property(env, result, "adler32", adler_v));
+    return result;
+}
+
+// checksum(u8) -> [crc32, adler32]
+napi_value Checksum(napi_env env, napi_callback_info info) {
+    if (!need_lib(env)) return nullptr;
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    const uint8_t *p = nullptr;
+    size_t len = 0;
+    if (argc < 1 || !get_u8(env, argv[0], &p, &len)) {
+        napi_throw_type_error(env, nullptr, "checksum(Uint8Array)");
+        return nullptr;
+    }
+    uint32_t c = 0, a = 1;
+    int rc = g.checksum(p, len, &c, &a);
+    if (rc) return throw_zgpu(env, "zgpu_checksum", rc);
+    napi_value arr, v0, v1;
+    NAPI_OK(napi_create_array_with_length(env, 2, &arr));
+    NAPI_OK(napi_create_uint32(env, c, &v0));
+    NAPI_OK(napi_create_uint32(env, a, &v1));
+    NAPI_OK(napi_set_element(env, arr, 0, v0));
+    NAPI_OK(napi_set_element(env, arr, 1, v1));
+    return arr;
+}
+
+napi_value combine(napi_env env, napi_callback_info info, bool crc) {
+    if (!need_lib(env)) return nullptr;
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    uint32_t a = 0, b = 0;
+    double len = 0;
+    NAPI_OK(napi_get_value_uint32(env, argv[0], &a));
+    NAPI_OK(napi_get_value_uint32(env, argv[1], &b));
+    NAPI_OK(napi_get_value_double(env, argv[2], &len));
+    uint32_t r = (crc ? g.crc_combine : g.adler_combine)(a, b, (uint64_t)len);
+    napi_value v;
+    NAPI_OK(napi_create_uint32(env, r, &v));
+    return v;
+}
+napi_value Crc32Combine(napi_env env, napi_callback_info info) { return combine(env, info, true); }
+napi_value Adler32Combine(napi_env env, napi_callback_info info) { return combine(env, info, false); }
+
+napi_value DeflateBound(napi_env env, napi_callback_info info) {
+    if (!need_lib(env)) return nullptr;
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    double n = 0;
+    NAPI_OK(napi_get_value_double(env, argv[0], &n));
+    napi_value v;
+    NAPI_OK(napi_create_double(env, (double)g.bound((uint64_t)n), &v));
+    return v;
+}
+
+napi_value SetSearch(napi_env env, napi_callback_info info) {
+    if (!need_lib(env)) return nullptr;
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    int32_t a = 0, b = 258;
+    NAPI_OK(napi_get_value_int32(env, argv[0], &a));
+    if (argc > 1) NAPI_OK(napi_get_value_int32(env, argv[1], &b));
+    int rc = g.set_search(a, b);
+    if (rc) return throw_zgpu(env, "zgpu_set_search", rc);
+    return nullptr;
+}
+
+napi_value SetMinLazy(napi_env env, napi_callback_info info) {
+    if (!need_lib(env)) return nullptr;
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    int32_t a = 0;
+    NAPI_OK(napi_get_value_int32(env, argv[0], &a));
+    int rc = g.set_min_lazy(a);
+    if (rc) return throw_zgpu(env, "zgpu_set_min_lazy", rc);
+    return nullptr;
+}
+
+napi_value ModuleInit(napi_env env, napi_value exports) {
+    const napi_property_descriptor props[] = {
+        {"init", nullptr, Init_, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"deflateBatch", nullptr, DeflateBatch, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"checksum", nullptr, Checksum, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"crc32Combine", nullptr, Crc32Combine, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"adler32Combine", nullptr, Adler32Combine, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"deflateBound", nullptr, DeflateBound, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setSearch", nullptr, SetSearch, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setMinLazy", nullptr, SetMinLazy, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+    };
+    if (napi_define_properties(env, exports, sizeof props / sizeof props[0], props) != napi_ok) return nullptr;
+    return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(zgpu_addon, ModuleInit)

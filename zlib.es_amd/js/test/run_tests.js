@@ -1,0 +1,186 @@
+'use strict';
+// The reference's compression tests restated against the GPU-backed shim
+// (cases of test/browser.es/zlib-test.js, raw-inflate-test.js,
+// code-path-test.js, gzip-test.js, zip-test.js and test/nodejs/node-test.js).
+// Decoding is done by Node's built-in zlib, as test/nodejs/node-test.js:195-221
+// does for cross-implementation conformance.  Needs a GPU.
+const assert = require('assert');
+const nodeZlib = require('zlib');
+const { Zlib, deflateChunked, gzipChunked } = require('../zlib_gpu.js');
+const H = require('./helpers.js');
+
+const size = 76543; // test/browser.es/zlib-test.js:7
+const CT = Zlib.RawDeflate.CompressionType;
+let passed = 0;
+function it(name, fn) {
+	fn();
+	++passed;
+	console.log('ok  ' + name);
+}
+const inputs = {
+	random: H.makeRandomData(size, 20121006),
+	sequential: H.makeSequentialData(size),
+	'random sequential': H.makeRandomSequentialData(size, 1346432776267),
+};
+
+// ---- checksums (src/crc32.js, src/adler32.js) ----
+it('CRC32 / Adler32 known answers', () => {
+	assert.strictEqual(Zlib.CRC32.calc(Buffer.from('123456789')), 0xcbf43926);
+	assert.strictEqual(Zlib.CRC32.calc(Buffer.from('hoge\n')), 0xb9e2879d); // unzip-test.js stored entry
+	assert.strictEqual(Zlib.Adler32.mkHash('Wikipedia'), 0x11e60398);
+	for (const k in inputs) {
+		assert.strictEqual(Zlib.CRC32.calc(inputs[k]), H.crc32(inputs[k]), k);
+		assert.strictEqual(Zlib.Adler32.mkHash(inputs[k]), H.adler32(inputs[k]), k);
+	}
+	const d = inputs.random;
+	assert.strictEqual(Zlib.CRC32.update(d.subarray(1000), Zlib.CRC32.calc(d.subarray(0, 1000))), H.crc32(d));
+	assert.strictEqual(Zlib.Adler32.update(Zlib.Adler32.mkHash(d.subarray(0, 1000)), d.subarray(1000)), H.adler32(d));
+	assert.strictEqual(Zlib.CRC32.calc(d, 10, 500), H.crc32(d.subarray(10, 510)));
+});
+
+// ---- zlib-test.js:15-84 / raw-inflate-test.js:25-108 ----
+for (const tname of ['NONE', 'FIXED', 'DYNAMIC'])
+	for (const k in inputs) {
+		it(`Deflate -> inflate: ${k} data, ${tname}`, () => {
+			const deflated = new Zlib.Deflate(inputs[k], { compressionType: CT[tname] }).compress();
+			const inflated = nodeZlib.inflateSync(Buffer.from(deflated)); // verifies the Adler-32 trailer
+			assert.ok(H.equal(inflated, inputs[k]));
+			assert.strictEqual(deflated.byteOffset, 0);
+		});
+		it(`RawDeflate -> rawinflate: ${k} data, ${tname}`, () => {
+			const deflated = new Zlib.RawDeflate(inputs[k], { compressionType: CT[tname] }).compress();
+			assert.ok(H.equal(nodeZlib.inflateRawSync(Buffer.from(deflated)), inputs[k]));
+		});
+	}
+it('undercomitted', () => {
+	const data = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23];
+	const compressed = new Zlib.Deflate(data).compress();
+	assert.ok(H.equal(nodeZlib.inflateSync(Buffer.from(compressed)), data));
+	assert.ok(H.equal(nodeZlib.inflateSync(Buffer.from(Zlib.Deflate.compress(data))), data));
+});
+
+// ---- code-path-test.js:21-31,41-202: the requested block maker is the one that runs ----
+it('code path: block makers are the executed call sites', () => {
+	const names = ['makeNocompressBlock', 'makeFixedHuffmanBlock', 'makeDynamicHuffmanBlock'];
+	const calls = {};
+	const orig = {};
+	for (const nm of names) {
+		orig[nm] = Zlib.RawDeflate.prototype[nm];
+		calls[nm] = 0;
+		Zlib.RawDeflate.prototype[nm] = function () {
+			calls[nm]++;
+			return orig[nm].apply(this, arguments);
+		};
+	}
+	try {
+		const want = { NONE: names[0], FIXED: names[1], DYNAMIC: names[2] };
+		for (const tname in want) {
+			for (const nm of names) calls[nm] = 0;
+			const out = new Zlib.Deflate(inputs.sequential, { compressionType: CT[tname] }).compress();
+			for (const nm of names) assert.strictEqual(calls[nm] > 0, nm === want[tname], `${tname}/${nm}`);
+			assert.ok(H.equal(nodeZlib.inflateSync(Buffer.from(out)), inputs.sequential));
+		}
+	} finally {
+		for (const nm of names) Zlib.RawDeflate.prototype[nm] = orig[nm];
+	}
+	assert.throws(() => new Zlib.RawDeflate(inputs.sequential, { compressionType: 3 }).compress());
+});
+
+// ---- lazy option (rawdeflate.js:86-87,339-347) ----
+it('lazy matching round trips and does not grow the output', () => {
+	const text = H.makeText(262144, 5);
+	const s0 = new Zlib.RawDeflate(text, { lazy: 0 }).compress();
+	const s32 = new Zlib.RawDeflate(text, { lazy: 32 }).compress();
+	assert.ok(H.equal(nodeZlib.inflateRawSync(Buffer.from(s32)), text));
+	assert.ok(s32.length <= s0.length);
+	const ref = nodeZlib.deflateRawSync(Buffer.from(text), { level: 6 });
+	assert.ok(s0.length < ref.length * 1.1, `${s0.length} vs zlib-6 ${ref.length}`);
+});
+
+// ---- gzip-test.js:21-76 ----
+it('Gzip -> gunzip (random sequential, fixed seed)', () => {
+	const data = inputs['random sequential'];
+	assert.ok(H.equal(nodeZlib.gunzipSync(Buffer.from(new Zlib.Gzip(data).compress())), data));
+});
+it('Gzip with filename, comment and header crc', () => {
+	const data = inputs.sequential;
+	const out = new Zlib.Gzip(data, { flags: { fname: true, fcomment: true, comment: true, fhcrc: true }, filename: 'foobar.filename', comment: 'hello' }).compress();
+	assert.strictEqual(out[3], 0x08 | 0x10 | 0x02);
+	assert.strictEqual(Buffer.from(out.subarray(10, 25)).toString(), 'foobar.filename');
+	assert.ok(H.equal(nodeZlib.gunzipSync(Buffer.from(out)), data));
+});
+
+// ---- zip-test.js:17-152 (STORE / DEFLATE entries; central directory parsed here) ----
+function unzip(z) {
+	let p = z.length - 22;
+	while (p >= 0 && !(z[p] === 0x50 && z[p + 1] === 0x4b && z[p + 2] === 5 && z[p + 3] === 6)) --p;
+	assert.ok(p >= 0, 'end of central directory');
+	const dv = new DataView(z.buffer, z.byteOffset, z.byteLength);
+	const count = dv.getUint16(p + 10, true);
+	let cd = dv.getUint32(p + 16, true);
+	const files = {};
+	for (let i = 0; i < count; ++i) {
+		assert.strictEqual(dv.getUint32(cd, true), 0x02014b50);
+		const method = dv.getUint16(cd + 10, true), crc = dv.getUint32(cd + 16, true);
+		const csize = dv.getUint32(cd + 20, true), usize = dv.getUint32(cd + 24, true);
+		const nlen = dv.getUint16(cd + 28, true), xlen = dv.getUint16(cd + 30, true), clen = dv.getUint16(cd + 32, true);
+		const off = dv.getUint32(cd + 42, true);
+		const name = Buffer.from(z.subarray(cd + 46, cd + 46 + nlen)).toString();
+		assert.strictEqual(dv.getUint32(off, true), 0x04034b50);
+		const lnlen = dv.getUint16(off + 26, true), lxlen = dv.getUint16(off + 28, true);
+		const body = z.subarray(off + 30 + lnlen + lxlen, off + 30 + lnlen + lxlen + csize);
+		const plain = method === 8 ? nodeZlib.inflateRawSync(Buffer.from(body)) : body;
+		assert.strictEqual(plain.length, usize, name);
+		assert.strictEqual(H.crc32(plain), crc, name);
+		files[name] = plain;
+		cd += 46 + nlen + xlen + clen;
+	}
+	return files;
+}
+it('Zip: STORE and DEFLATE entries, batched compress()', () => {
+	const td = { hogehoge: H.makeText(30000, 1), fugafuga: inputs.sequential.subarray(0, 5000), piyopiyo: inputs.random.subarray(0, 4000), empty: new Uint8Array(0) };
+	const zip = new Zlib.Zip();
+	let i = 0;
+	for (const key in td) {
+		const opt = { filename: new Uint8Array(Buffer.from(key)) };
+		if (i % 3 === 1) opt.compressionMethod = Zlib.Zip.CompressionMethod.STORE;
+		if (i % 3 === 2) opt.deflateOption = { compressionType: CT.FIXED };
+		zip.addFile(td[key], opt);
+		++i;
+	}
+	const files = unzip(zip.compress());
+	for (const key in td) assert.ok(H.equal(files[key], td[key]), key);
+});
+it('Zip: many small files in one batch', () => {
+	const zip = new Zlib.Zip();
+	const td = [];
+	const mt = new H.MT(99);
+	for (let f = 0; f < 300; ++f) {
+		const n = 1 + (mt.next() % 16384);
+		const d = f % 4 === 3 ? H.makeRandomData(n, f) : H.makeText(n, f);
+		td.push(d);
+		zip.addFile(d, { filename: new Uint8Array(Buffer.from('f' + f)), deflateOption: { compressionType: f & 1 ? CT.FIXED : CT.DYNAMIC } });
+	}
+	const files = unzip(zip.compress());
+	td.forEach((d, f) => assert.ok(H.equal(files['f' + f], d), 'f' + f));
+});
+
+// ---- chunked single-member streams (sync-aligned chunks + checksum combine) ----
+it('gzipChunked: one member, many independently compressed chunks', () => {
+	const data = H.makeText(3 * 1048576 + 12345, 7);
+	const gz = gzipChunked(data, { chunkSize: 1 << 20, mtime: 0 });
+	assert.ok(H.equal(nodeZlib.gunzipSync(Buffer.from(gz)), data)); // checks CRC-32 and ISIZE
+	const d = deflateChunked(data, { chunkSize: 65536 });
+	assert.strictEqual(d.crc32, H.crc32(data));
+	assert.strictEqual(d.adler32, H.adler32(data));
+	assert.ok(H.equal(nodeZlib.inflateRawSync(Buffer.concat(d.parts.map((p) => Buffer.from(p)))), data));
+});
+
+// ---- batch API ----
+it('RawDeflate.compressBatch', () => {
+	const ins = [inputs.random.subarray(0, 1000), inputs.sequential, H.makeText(100000, 3), new Uint8Array(0), new Uint8Array([65])];
+	const outs = Zlib.RawDeflate.compressBatch(ins, { compressionType: CT.DYNAMIC });
+	ins.forEach((d, i) => assert.ok(H.equal(nodeZlib.inflateRawSync(Buffer.from(outs[i])), d), 'unit ' + i));
+});
+
+console.log(`${passed} tests passed`);
