@@ -183,4 +183,24 @@ it('RawDeflate.compressBatch', () => {
 	ins.forEach((d, i) => assert.ok(H.equal(nodeZlib.inflateRawSync(Buffer.from(outs[i])), d), 'unit ' + i));
 });
 
-console.log(`${passed} tests passed`);
+// ---- Node wrapper, compress side (test/nodejs/node-test.js:101-131, node/exports.js:52-69,150-165) ----
+it('deflateSync / gzipSync return Buffers that Node inflates', () => {
+	const W = require('../zlib_gpu.js');
+	const data = inputs['random sequential'];
+	const d = W.deflateSync(data);
+	assert.ok(Buffer.isBuffer(d));
+	assert.ok(H.equal(nodeZlib.inflateSync(d), data));
+	const f = W.deflateSync(data, { deflateOption: { compressionType: CT.FIXED }, noBuffer: true });
+	assert.ok(f instanceof Uint8Array && !Buffer.isBuffer(f));
+	assert.ok(H.equal(nodeZlib.inflateSync(Buffer.from(f)), data));
+	assert.ok(H.equal(nodeZlib.gunzipSync(W.gzipSync(data)), data));
+	let called = false;
+	W.deflate(data, (err, out) => {
+		called = true;
+		assert.ok(!err);
+		assert.ok(H.equal(nodeZlib.inflateSync(out), data));
+	});
+	assert.strictEqual(called, false); // runs on the next tick
+});
+
+process.on('exit', () => console.log(`${passed} tests passed`));

@@ -482,5 +482,36 @@ function gzipChunked(input, opt) {
 	return out;
 }
 
+// compress side of the Node wrapper (reference node/exports.js:28-69,127-165):
+// deflateSync takes {deflateOption, noBuffer}; gzipSync ignores every option
+// but noBuffer; the callback forms run on the next tick and pass (error, data).
+function deflateSync(buffer, optParams) {
+	const o = optParams || {};
+	const out = new Deflate(buffer, o.deflateOption || {}).compress();
+	return o.noBuffer ? out : Buffer.from(out);
+}
+function gzipSync(buffer, optParams) {
+	const out = new Gzip(buffer).compress();
+	return optParams && optParams.noBuffer ? out : Buffer.from(out);
+}
+function nextTickForm(fn) {
+	return function (buffer, callback, optParams) {
+		process.nextTick(() => {
+			let error, data;
+			try {
+				data = fn(buffer, optParams);
+			} catch (e) {
+				error = e;
+			}
+			callback(error, data);
+		});
+	};
+}
+const deflate = nextTickForm(deflateSync);
+const gzip = nextTickForm(gzipSync);
+
 const Zlib = { RawDeflate, Deflate, Gzip, Zip, CRC32, Adler32 };
-module.exports = { Zlib, RawDeflate, Deflate, Gzip, Zip, CRC32, Adler32, deflateChunked, gzipChunked, addon };
+module.exports = {
+	Zlib, RawDeflate, Deflate, Gzip, Zip, CRC32, Adler32, deflateChunked, gzipChunked,
+	deflate, deflateSync, gzip, gzipSync, addon,
+};
