@@ -144,6 +144,19 @@ __device__ inline void load_ring(uint8_t *ring, const uint8_t *in, uint32_t lo, 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __device__ inline uint32_t ld4(const uint8_t *p) { return *(const u32_unaligned *)p; }
 
+// 16 bytes at any LDS address in one instruction, and the number of leading
+// bytes (0..16) in which two such pieces agree
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef v4u __attribute__((aligned(1))) v4u_unaligned;
+__device__ inline v4u ld16(const uint8_t *p) { return *(const v4u_unaligned *)p; }
+__device__ inline uint32_t mlen16(v4u a, v4u b) {
+    const v4u x = a ^ b;
+    const uint64_t lo = (uint64_t)x.x | ((uint64_t)x.y << 32), hi = (uint64_t)x.z | ((uint64_t)x.w << 32);
+    if (lo) return (uint32_t)__builtin_ctzll(lo) >> 3;
+    if (hi) return 8u + ((uint32_t)__builtin_ctzll(hi) >> 3);
+    return 16u;
+}
+
 __device__ inline uint32_t hash3(uint32_t w) {
     return ((w & 0xffffffu) * 0x9E3779B1u) >> (32 - HBITS);
 }
@@ -198,19 +211,23 @@ __device__ inline void bitonic_sort(uint32_t *a, int n) {
 // the workgroup, so a wave that has drained its own LDS queue (lgkmcnt(0)) may
 // publish, and a wave that has seen the value may read what was written before
 // it.  Only LDS is ordered here: no global-memory fence is involved.
+// The words are accessed through explicit LDS-address-space pointers: a volatile
+// access through a generic pointer would be issued as a (much slower) flat
+// instruction.
+typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
+__device__ inline uint32_t lds_ld(const uint32_t *word) { return *(lds_vu32 *)word; }
+__device__ inline void lds_st(uint32_t *word, uint32_t value) { *(lds_vu32 *)word = value; }
 __device__ inline void lds_wait_eq(uint32_t *word, uint32_t want) {
-    volatile uint32_t *w = word;
-    while (*w != want) __builtin_amdgcn_s_sleep(0);
+    while (lds_ld(word) != want) __builtin_amdgcn_s_sleep(0);
     asm volatile("" ::: "memory");
 }
 __device__ inline void lds_wait_ge(uint32_t *word, uint32_t want) {
-    volatile uint32_t *w = word;
-    while ((int32_t)(*w - want) < 0) __builtin_amdgcn_s_sleep(0);
+    while ((int32_t)(lds_ld(word) - want) < 0) __builtin_amdgcn_s_sleep(0);
     asm volatile("" ::: "memory");
 }
 __device__ inline void lds_publish(uint32_t *word, uint32_t value) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if ((threadIdx.x & 63) == 0) *(volatile uint32_t *)word = value;
+    if ((threadIdx.x & 63) == 0) lds_st(word, value);
 }
 
 // bitonic sort of one key per lane across the wave (ascending by lane), in registers
@@ -668,7 +685,7 @@ zgpu_deflate_kernel(Params P) {
                     for (;;) {
                         if (atomicCAS(&misc[M_LOCK], 0u, 1u) != 0u) break;  // someone else is at it
                         uint32_t f = misc[M_PARSE], e = misc[M_ENTRY], t = misc[M_NTOK];
-                        while (*(volatile uint32_t *)&slot_done[f & (NSLOT - 1)] == f + 1) {
+                        while (lds_ld(&slot_done[f & (NSLOT - 1)]) == f + 1) {
                             const uint32_t sl = f & (NSLOT - 1), le = e - (f << 6);
                             slot_entry[sl] = e;
                             slot_tokb[sl] = t;
@@ -681,11 +698,11 @@ zgpu_deflate_kernel(Params P) {
                         misc[M_ENTRY] = e;
                         misc[M_NTOK] = t;
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        *(volatile uint32_t *)&misc[M_PARSE] = f;
+                        lds_st(&misc[M_PARSE], f);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        *(volatile uint32_t *)&misc[M_LOCK] = 0u;
+                        lds_st(&misc[M_LOCK], 0u);
                         // an item stamped while the lock was held must not be left behind
-                        if (*(volatile uint32_t *)&slot_done[f & (NSLOT - 1)] != f + 1) break;
+                        if (lds_ld(&slot_done[f & (NSLOT - 1)]) != f + 1) break;
                     }
                 }
             };
@@ -712,7 +729,7 @@ zgpu_deflate_kernel(Params P) {
                 return (uint32_t)lane + adv;
             };
             auto resolved = [&](uint32_t k0) -> bool {
-                return (int32_t)(*(volatile uint32_t *)&misc[M_PARSE] - k0) > 0;
+                return (int32_t)(lds_ld(&misc[M_PARSE]) - k0) > 0;
             };
             auto emit_oldest = [&]() {
                 // ---- tokens of item q_k[0], in registers: lane l <-> local index l ----
@@ -843,20 +860,18 @@ zgpu_deflate_kernel(Params P) {
                     const uint32_t limit = p < MAXDIST ? p : MAXDIST;
                     uint32_t blen = 2;
                     {
-                        // pass 1, lane per position: walk the hash chain.  The LDS pipe is the
-                        // scarce resource (random addresses conflict on banks), so a candidate
-                        // costs two LDS reads: its chain link and ONE unaligned dword -- the four
-                        // bytes ending at the current best length (the first four while nothing
-                        // is in hand).  Only a candidate that passes this test is compared from
-                        // the start, four bytes a step, up to CMP_CAP bytes (pass 2 finds the
-                        // exact length of long matches).
+                        // pass 1, lane per position: walk the hash chain.  A candidate costs one
+                        // LDS round trip: its chain link and its first 16 bytes (one unaligned
+                        // 128-bit read) are fetched together and compared against this position's
+                        // 16 bytes held in registers, so there is no per-lane compare loop for the
+                        // wave to diverge on.  Only a candidate that matches all 16 bytes reads 16
+                        // more (CMP_CAP; pass 2 finds the exact length of long matches).
                         const uint32_t pi = p & (RING - 1);
                         const uint32_t cmpmax = maxlen < CMP_CAP ? maxlen : CMP_CAP;
                         const uint32_t stop = cmpmax < (uint32_t)P.nice ? cmpmax : (uint32_t)P.nice;
                         if (p + 3 <= n) {
                             uint32_t c = prevt[p & WMASK];
-                            uint32_t toff = 0;                 // offset of the test dword
-                            uint32_t ptail = ld4(ring + pi);   // this position's bytes at toff
+                            const v4u own = ld16(ring + pi);
                             uint32_t last = 0;
                             for (int budget = P.max_chain; budget > 0; --budget) {
                                 const uint32_t dist = (p - c) & 0xffffu;
@@ -864,27 +879,14 @@ zgpu_deflate_kernel(Params P) {
                                 last = dist;
                                 const uint32_t ci = c & (RING - 1);
                                 const uint32_t nxt = prevt[c & WMASK];
-                                const uint32_t x = ld4(ring + ci + toff) ^ ptail;
-                                if (blen < 3 ? (x & 0xffffffu) == 0 : x == 0) {
-                                    uint32_t len = 0;
-                                    if (toff == 0) len = x ? 3u : 4u;
-                                    if (!(toff == 0 && x))
-                                        while (len < cmpmax) {
-                                            const uint32_t x2 = ld4(ring + ci + len) ^ ld4(ring + pi + len);
-                                            if (x2) {
-                                                len += (uint32_t)__builtin_ctz(x2) >> 3;
-                                                break;
-                                            }
-                                            len += 4;
-                                        }
-                                    if (len > cmpmax) len = cmpmax;
-                                    if (len > blen) {
-                                        blen = len;
-                                        best_dist = dist;
-                                        if (len >= stop) break;
-                                        toff = len - 3;  // next test: bytes len-3 .. len
-                                        ptail = ld4(ring + pi + toff);
-                                    }
+                                uint32_t len = mlen16(own, ld16(ring + ci));
+                                if (len == 16 && cmpmax > 16)
+                                    len = 16 + mlen16(ld16(ring + pi + 16), ld16(ring + ci + 16));
+                                if (len > cmpmax) len = cmpmax;
+                                if (len > blen) {
+                                    blen = len;
+                                    best_dist = dist;
+                                    if (len >= stop) break;
                                 }
                                 c = nxt;
                             }
