@@ -53,6 +53,8 @@ constexpr uint32_t SHARE_MIN = 16;  // matches at least this long offer their di
 constexpr int SHARE_ITERS = 6;      // distinct distances scored per wave
 constexpr int STAGE_WORDS = 1792;   // bit staging (>= header + 1024*48/32 + carry)
 
+constexpr uint32_t huf_scratch_bytes(uint32_t cap) { return 17 * cap + 128; }  // see HufS
+
 // ---- LDS map (bytes) -------------------------------------------------------
 constexpr uint32_t L_RING = 0;
 constexpr uint32_t L_PREV = L_RING + RING + RING_PAD;      // u16[32768]
@@ -79,16 +81,16 @@ constexpr uint32_t S_LLTAB = S_STAGE + STAGE_WORDS * 4;  // u32[288] code | len<
 constexpr uint32_t S_DTAB = S_LLTAB + 288 * 4;           // u32[32]
 constexpr uint32_t S_HUF = S_DTAB + 32 * 4;              // Huffman build scratch
 constexpr uint32_t HUF_BYTES = SCR_BYTES - S_HUF;
-// Huffman build scratch map (bytes from S_HUF)
-constexpr uint32_t H_KEY = 0;        // u32[512] sort keys
-constexpr uint32_t H_PARENT = 2048;  // u16[640]
-constexpr uint32_t H_IW = 3328;      // u32[288] internal weights / depths / first codes
-constexpr uint32_t H_LENS = 4480;    // u8[288]
-constexpr uint32_t H_CLF = 4768;     // u32[20] code-length symbol freqs
-constexpr uint32_t H_CLTAB = 4848;   // u32[20]
-constexpr uint32_t H_RLE = 4928;     // u16[320]
-constexpr uint32_t H_NRLE = 5568;    // u32
-static_assert(HUF_BYTES >= 5572, "huffman scratch");
+// Huffman build scratch map (bytes from S_HUF): the lit/len tree, then the
+// distance tree (reused for the code-length tree); once the lit/len and
+// distance codes exist, the run-length items of the header reuse the first.
+constexpr uint32_t H_TL = 0;
+constexpr uint32_t H_TD = H_TL + huf_scratch_bytes(288);
+constexpr uint32_t H_END = H_TD + huf_scratch_bytes(32);
+constexpr uint32_t H_RLE = 0;      // u16[320] items: symbol | extra << 8
+constexpr uint32_t H_CLF = 640;    // u32[32] code-length symbol freqs
+constexpr uint32_t H_CLTAB = 768;  // u32[32]
+static_assert(H_END <= HUF_BYTES, "huffman scratch");
 
 // misc words
 enum { M_SCAN = 0 /*[16]*/, M_UNIT = 32, M_NTOK = 34, M_TMP = 35, M_OVF = 36,
@@ -293,105 +295,199 @@ struct BitW {
 };
 
 // ---- Huffman code lengths (length-limited), canonical codes ----------------
-// freq[0..nsym) -> len[0..nsym), bit-reversed codes packed as code | len<<16 in
-// tab[].  The workgroup sorts; thread 0 runs the two-queue tree build and the
-// overflow repair.  At least two symbols get a code so every code set is
-// complete.  scratch: >= 4096 bytes.
-__device__ void build_codes(uint32_t *freq, int nsym, int maxbits, uint32_t *tab, uint8_t *scratch) {
-    const int t = threadIdx.x;
-    uint32_t *key = (uint32_t *)(scratch + H_KEY);
-    uint16_t *parent = (uint16_t *)(scratch + H_PARENT);
-    uint32_t *iw = (uint32_t *)(scratch + H_IW);
-    uint8_t *lens = scratch + H_LENS;  // code length per symbol
-    if (t == 0) {
-        int nz = 0;
-        for (int i = 0; i < nsym && nz < 2; ++i) nz += freq[i] != 0;
-        // force two coded symbols (keeps the code complete)
-        for (int i = 0; nz < 2 && i < nsym; ++i)
-            if (freq[i] == 0) {
-                freq[i] = 1;
-                ++nz;
-            }
-    }
-    __syncthreads();
-    if (t < 512) key[t] = (t < nsym && freq[t]) ? ((freq[t] << 9) | (uint32_t)t) : 0xffffffffu;
-    __syncthreads();
-    bitonic_sort(key, 512);
-    if (t < 288) lens[t] = 0;
-    __syncthreads();
-    if (t == 0) {
-        int m = 0;
-        while (m < nsym && key[m] != 0xffffffffu) ++m;
-        // two-queue merge: leaves 0..m-1 (ascending weight), internal m..2m-2
-        int li = 0, ii = 0;
-        for (int k = 0; k < m - 1; ++k) {
+// One wave builds the code of one alphabet; the control flow is wave-uniform
+// and the serial part (the two-queue merge) runs on scalar registers.
+__device__ inline uint32_t rl(uint32_t v, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+__device__ inline uint32_t wl(uint32_t old, uint32_t val, uint32_t l) {
+    return (threadIdx.x & 63u) == l ? val : old;  // val and l are wave-uniform
+}
+
+struct HufS {          // LDS scratch of one tree, cap = alphabet size rounded up to 32
+    uint32_t *sorted;  // [cap] keys (weight << 9 | symbol), ascending; m of them are real
+    uint32_t *niw;     // [cap] weights of the internal nodes (sort keys before that)
+    uint16_t *cl;      // [cap] leaves consumed after merge step k
+    uint16_t *parN;    // [cap] parent of internal node
+    uint16_t *parL;    // [cap] parent of leaf (by sorted index)
+    uint16_t *dep;     // [cap] depth of internal node
+    uint32_t *blc;     // [32]  symbols per code length
+    uint8_t *lens;     // [cap] code length per symbol
+    uint32_t *rank;    // [cap] sort ranks (aliases cl, parN)
+};
+__device__ inline HufS huf_scratch(uint8_t *base, uint32_t cap) {
+    HufS S;
+    S.sorted = (uint32_t *)base;
+    S.niw = (uint32_t *)(base + 4 * cap);
+    S.cl = (uint16_t *)(base + 8 * cap);
+    S.parN = (uint16_t *)(base + 10 * cap);
+    S.parL = (uint16_t *)(base + 12 * cap);
+    S.dep = (uint16_t *)(base + 14 * cap);
+    S.blc = (uint32_t *)(base + 16 * cap);
+    S.lens = base + 16 * cap + 128;
+    S.rank = (uint32_t *)(base + 8 * cap);
+    return S;
+}
+
+// S.sorted[0..m) holds the used symbols' keys in ascending order, m >= 2.
+// Writes tab[s] = bit-reversed canonical code | length << 16 (0 for unused
+// symbols) for s < nsym.  NCH = ceil(alphabet / 64).
+template <int NCH>
+__device__ void wave_huffman(const HufS &S, uint32_t m_in, uint32_t nsym, uint32_t maxbits, uint32_t *tab) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)m_in);
+    const uint32_t INF = 0xffffffffu;
+    for (uint32_t sy = lane; sy < nsym; sy += 64) S.lens[sy] = 0;
+    if (lane < 32) S.blc[lane] = 0;
+    // ---- two-queue merge.  Leaves and internal nodes are each consumed in order, so a
+    // 64-entry register window per queue (refilled from LDS every 64 entries) feeds the
+    // heads through readlane; node k's weight goes to LDS and, when it falls into the
+    // current window, into the window register as well.
+    {
+        uint32_t li = 0, ii = 0;
+        uint32_t lwin = lane < m ? S.sorted[lane] >> 9 : INF;
+        uint32_t nwin = INF;
+        uint32_t lhead = rl(lwin, 0), nhead = INF;
+        for (uint32_t k = 0; k + 1 < m; ++k) {
             uint32_t w = 0;
+#pragma unroll
             for (int r = 0; r < 2; ++r) {
-                bool take_leaf;
-                if (li >= m)
-                    take_leaf = false;
-                else if (ii >= k)
-                    take_leaf = true;
-                else
-                    take_leaf = (key[li] >> 9) <= iw[ii];
-                if (take_leaf) {
-                    w += key[li] >> 9;
-                    parent[li++] = (uint16_t)(m + k);
+                if (lhead <= nhead) {
+                    w += lhead;
+                    ++li;
+                    if ((li & 63u) == 0) lwin = li + lane < m ? S.sorted[li + lane] >> 9 : INF;
+                    lhead = rl(lwin, li & 63u);
                 } else {
-                    w += iw[ii];
-                    parent[m + ii++] = (uint16_t)(m + k);
+                    w += nhead;
+                    ++ii;
+                    if ((ii & 63u) == 0) nwin = ii + lane < k ? S.niw[ii + lane] : INF;
+                    nhead = rl(nwin, ii & 63u);
                 }
             }
-            iw[k] = w;
-        }
-        // depths top-down (reuse iw as depth of internal nodes)
-        uint32_t blc[32];
-        for (int b = 0; b < 32; ++b) blc[b] = 0;
-        iw[m - 2] = 0;
-        for (int k = m - 3; k >= 0; --k) iw[k] = iw[parent[m + k] - m] + 1;
-        int overflow = 0;
-        for (int i = 0; i < m; ++i) {
-            int d = (int)iw[parent[i] - m] + 1;
-            if (d > maxbits) {
-                d = maxbits;
-                ++overflow;
+            if (lane == 0) {
+                S.niw[k] = w;
+                S.cl[k] = (uint16_t)li;
             }
-            blc[d]++;
+            if ((k >> 6) == (ii >> 6)) {
+                nwin = wl(nwin, w, k & 63u);
+                if (ii == k) nhead = w;
+            }
         }
-        // Kraft repair: move the deepest leaves up until the code fits
-        while (overflow > 0) {
-            int bits = maxbits - 1;
-            while (blc[bits] == 0) --bits;
-            blc[bits]--;
-            blc[bits + 1] += 2;
-            blc[maxbits]--;
-            overflow -= 2;
+    }
+    // ---- parents: step k consumed leaves [cl[k-1], cl[k]) and nodes [2k - cl[k-1], 2k + 2 - cl[k])
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const uint32_t k = (uint32_t)c * 64 + lane;
+        if (k + 1 < m) {
+            const uint32_t c0 = k ? S.cl[k - 1] : 0u, c1 = S.cl[k];
+            for (uint32_t i = c0; i < c1; ++i) S.parL[i] = (uint16_t)k;
+            for (uint32_t j = 2 * k - c0; j < 2 * k + 2 - c1; ++j) S.parN[j] = (uint16_t)k;
+            S.dep[k] = 1;
         }
-        // assign lengths in sorted order: rarest symbols get the longest codes
-        int r = 0;
-        for (int b = maxbits; b >= 1; --b)
-            for (uint32_t c = 0; c < blc[b]; ++c) lens[key[r++] & 511] = (uint8_t)b;
-        // canonical first codes per length
+    }
+    if (lane == 0) {
+        S.parN[m - 2] = (uint16_t)(m - 2);  // the root
+        S.dep[m - 2] = 0;
+    }
+    // ---- depth of every internal node by pointer jumping (reads of a round precede its writes)
+    for (int round = 0; round < 10; ++round) {
+        uint32_t np[NCH], nd[NCH];
+        bool more = false;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const uint32_t k = (uint32_t)c * 64 + lane;
+            np[c] = 0;
+            nd[c] = 0;
+            if (k + 1 < m) {
+                const uint32_t pp = S.parN[k];
+                np[c] = S.parN[pp];
+                nd[c] = (uint32_t)S.dep[k] + S.dep[pp];
+                more = more || np[c] != m - 2;
+            }
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const uint32_t k = (uint32_t)c * 64 + lane;
+            if (k + 1 < m) {
+                S.parN[k] = (uint16_t)np[c];
+                S.dep[k] = (uint16_t)nd[c];
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (!__ballot(more)) break;
+    }
+    // ---- symbols per code length; depths beyond the limit are clamped and repaired
+    uint32_t overflow = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const uint32_t i = (uint32_t)c * 64 + lane;
+        bool over = false;
+        if (i < m) {
+            uint32_t d = (uint32_t)S.dep[S.parL[i]] + 1;
+            over = d > maxbits;
+            if (over) d = maxbits;
+            atomicAdd(&S.blc[d], 1u);
+        }
+        overflow += (uint32_t)__builtin_popcountll(__ballot(over));
+    }
+    if (overflow && lane == 0) {
+        // move the deepest leaves up until the code fits
+        int ov = (int)overflow;
+        while (ov > 0) {
+            uint32_t bits = maxbits - 1;
+            while (S.blc[bits] == 0) --bits;
+            S.blc[bits]--;
+            S.blc[bits + 1] += 2;
+            S.blc[maxbits]--;
+            ov -= 2;
+        }
+    }
+    asm volatile("" ::: "memory");
+    const uint32_t blcv = lane < 32 ? S.blc[lane] : 0u;
+    // ---- lengths in sorted order: the rarest symbols get the longest codes
+    {
+        uint32_t len[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) len[c] = 0;
+        uint32_t acc = 0;
+        for (uint32_t b = maxbits; b >= 1; --b) {
+            const uint32_t nb = rl(blcv, b);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                if (len[c] == 0 && (uint32_t)c * 64 + lane < acc + nb) len[c] = b;
+            acc += nb;
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const uint32_t i = (uint32_t)c * 64 + lane;
+            if (i < m) S.lens[S.sorted[i] & 511u] = (uint8_t)len[c];
+        }
+    }
+    // ---- canonical codes: first code per length, then symbols in index order
+    uint32_t nextv = 0;
+    {
         uint32_t code = 0;
-        uint32_t *next = iw;  // reuse [0..16)
-        for (int b = 1; b <= maxbits; ++b) {
-            code = (code + blc[b - 1]) << 1;
-            next[b] = code;
+        for (uint32_t b = 1; b <= maxbits; ++b) {
+            code = (code + (b > 1 ? rl(blcv, b - 1) : 0u)) << 1;
+            nextv = wl(nextv, code, b);
         }
     }
-    __syncthreads();
-    // canonical code of symbol t = first[len] + #{s < t : len[s] == len[t]}
-    if (t < nsym) {
-        uint32_t l = lens[t], v = 0;
-        if (l) {
-            uint32_t rank = 0;
-            for (int s = 0; s < t; ++s) rank += lens[s] == l;
-            uint32_t c = iw[l] + rank;
-            v = (__brev(c) >> (32 - l)) | (l << 16);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const uint32_t sy = (uint32_t)c * 64 + lane;
+        const uint32_t l = sy < nsym ? (uint32_t)S.lens[sy] : 0u;
+        uint32_t code = 0;
+        for (uint32_t b = 1; b <= maxbits; ++b) {
+            if (rl(blcv, b) == 0) continue;
+            const unsigned long long mk = __ballot(l == b);
+            const uint32_t base = rl(nextv, b);
+            if (l == b) code = base + (uint32_t)__builtin_popcountll(mk & lt);
+            nextv = wl(nextv, base + (uint32_t)__builtin_popcountll(mk), b);
         }
-        tab[t] = v;
+        if (sy < nsym) tab[sy] = l ? ((__brev(code) >> (32 - l)) | (l << 16)) : 0u;
     }
-    __syncthreads();
 }
 
 struct Params {
@@ -485,88 +581,255 @@ zgpu_deflate_kernel(Params P) {
             if (tid == 0) stage[0] = carry_word;
             BitW bw{stage, bitpos - base_word * 32};
             if (P.ctype == 2) {
-                build_codes(fl, 286, 15, lltab, scr + S_HUF);
-                build_codes(fd, 30, 15, dtab, scr + S_HUF);
-                // ---- header: HLIT/HDIST, RLE of code lengths, code-length code ----
-                uint32_t *clf = (uint32_t *)(scr + S_HUF + H_CLF);      // freqs of symbols 0..18
-                uint32_t *cltab = (uint32_t *)(scr + S_HUF + H_CLTAB);
-                uint16_t *rle = (uint16_t *)(scr + S_HUF + H_RLE);      // sym | extra<<8
-                uint32_t *nrle = (uint32_t *)(scr + S_HUF + H_NRLE);
-                if (tid < 20) clf[tid] = 0;
-                __syncthreads();
-                if (tid == 0) {
-                    int hlit = 286, hdist = 30;
-                    while (hlit > 257 && (lltab[hlit - 1] >> 16) == 0) --hlit;
-                    while (hdist > 1 && (dtab[hdist - 1] >> 16) == 0) --hdist;
-                    const int tot = hlit + hdist;
-                    int nr = 0;
-                    for (int i = 0; i < tot;) {
-                        const uint32_t v = i < hlit ? lltab[i] >> 16 : dtab[i - hlit] >> 16;
-                        int run = 1;
-                        while (i + run < tot) {
-                            const int k = i + run;
-                            const uint32_t w = k < hlit ? lltab[k] >> 16 : dtab[k - hlit] >> 16;
-                            if (w != v) break;
-                            ++run;
-                        }
-                        i += run;
-                        if (v == 0) {
-                            while (run >= 11) {
-                                int r = run > 138 ? 138 : run;
-                                rle[nr++] = (uint16_t)(18 | ((r - 11) << 8));
-                                clf[18]++;
-                                run -= r;
-                            }
-                            if (run >= 3) {
-                                rle[nr++] = (uint16_t)(17 | ((run - 3) << 8));
-                                clf[17]++;
-                                run = 0;
-                            }
-                            while (run-- > 0) {
-                                rle[nr++] = 0;
-                                clf[0]++;
-                            }
-                        } else {
-                            rle[nr++] = (uint16_t)v;
-                            clf[v]++;
-                            --run;
-                            while (run >= 3) {
-                                int r = run > 6 ? 6 : run;
-                                rle[nr++] = (uint16_t)(16 | ((r - 3) << 8));
-                                clf[16]++;
-                                run -= r;
-                            }
-                            while (run-- > 0) {
-                                rle[nr++] = (uint16_t)v;
-                                clf[v]++;
-                            }
-                        }
+                const HufS TL = huf_scratch(scr + S_HUF + H_TL, 288), TD = huf_scratch(scr + S_HUF + H_TD, 32);
+                const uint32_t INF = 0xffffffffu;
+                // every code set gets at least two symbols, so it is complete: a block that
+                // holds only the end-of-block symbol gains literal 0, and the distance
+                // alphabet is topped up to two used symbols
+                if (tid == 0 && misc[M_NTOK] < 2) fl[0] = 1;
+                if (wave == 1) {
+                    const unsigned long long nz = __ballot(lane < 30 && fd[lane] != 0);
+                    const int c = __builtin_popcountll(nz);
+                    if (c < 2 && lane == 0) {
+                        if (c == 0) fd[0] = 1;
+                        fd[(c == 0 || (nz & 1ull)) ? 1 : 0] = 1;
                     }
-                    *nrle = (uint32_t)nr | ((uint32_t)hlit << 16) | ((uint32_t)hdist << 26);
                 }
                 __syncthreads();
-                build_codes(clf, 19, 7, cltab, scr + S_HUF);
-                if (tid == 0) {
-                    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5,
-                                               11, 4, 12, 3, 13, 2, 14, 1, 15};
-                    const uint32_t pk = *nrle;
-                    const int nr = pk & 0xffff, hlit = (pk >> 16) & 0x3ff, hdist = pk >> 26;
-                    int hclen = 19;
-                    while (hclen > 4 && (cltab[order[hclen - 1]] >> 16) == 0) --hclen;
-                    bw.put(bfinal, 1);
-                    bw.put(2, 2);
-                    bw.put((uint32_t)(hlit - 257), 5);
-                    bw.put((uint32_t)(hdist - 1), 5);
-                    bw.put((uint32_t)(hclen - 4), 4);
-                    for (int i = 0; i < hclen; ++i) bw.put(cltab[order[i]] >> 16, 3);
-                    for (int i = 0; i < nr; ++i) {
-                        const uint32_t sym = rle[i] & 0xff, ex = rle[i] >> 8;
-                        bw.put(cltab[sym] & 0xffff, cltab[sym] >> 16);
-                        if (sym == 16) bw.put(ex, 2);
-                        if (sym == 17) bw.put(ex, 3);
-                        if (sym == 18) bw.put(ex, 7);
+                // ---- sort keys (weight << 9 | symbol, unused = INF) and rank sort ----
+                if (tid < 288) {
+                    TL.niw[tid] = (tid < 286 && fl[tid]) ? ((fl[tid] << 9) | (uint32_t)tid) : INF;
+                    TL.rank[tid] = 0;
+                } else if (tid < 320) {
+                    const int d = tid - 288;
+                    TD.niw[d] = (d < 30 && fd[d]) ? ((fd[d] << 9) | (uint32_t)d) : INF;
+                }
+                __syncthreads();
+                if (tid < 864) {
+                    // three threads per lit/len key, each counting the smaller keys in a third
+                    const int i = tid % 288, part = tid / 288;
+                    const uint32_t me = TL.niw[i];
+                    const uint4 *kp = (const uint4 *)(TL.niw + part * 96);
+                    uint32_t cnt = 0;
+#pragma unroll 4
+                    for (int j = 0; j < 24; ++j) {
+                        const uint4 q = kp[j];
+                        cnt += (q.x < me) + (q.y < me) + (q.z < me) + (q.w < me);
                     }
-                    misc[M_TMP] = bw.rel;
+                    atomicAdd(&TL.rank[i], cnt);
+                } else if (tid < 896) {
+                    const int d = tid - 864;
+                    const uint32_t me = TD.niw[d];
+                    uint32_t cnt = 0;
+                    for (int j = 0; j < 32; ++j) cnt += TD.niw[j] < me;
+                    TD.rank[d] = cnt;
+                }
+                __syncthreads();
+                // a padding key's rank is the number of used symbols
+                const uint32_t mL = TL.rank[287], mD = TD.rank[31];
+                uint32_t myrank = 0, mykey = INF;
+                if (tid < 288) {
+                    myrank = TL.rank[tid];
+                    mykey = TL.niw[tid];
+                } else if (tid < 320) {
+                    myrank = TD.rank[tid - 288];
+                    mykey = TD.niw[tid - 288];
+                }
+                if (mykey != INF) (tid < 288 ? TL.sorted : TD.sorted)[myrank] = mykey;
+                __syncthreads();
+                // ---- the two trees, one wave each ----
+                if (wave == 0) wave_huffman<5>(TL, mL, 286, 15, lltab);
+                if (wave == 1) wave_huffman<1>(TD, mD, 30, 15, dtab);
+                __syncthreads();
+                // ---- header (wave 0): HLIT/HDIST, run-length items, code-length code, bits ----
+                if (wave == 0) {
+                    uint16_t *rle = (uint16_t *)(scr + S_HUF + H_RLE);
+                    uint32_t *clf = (uint32_t *)(scr + S_HUF + H_CLF);
+                    uint32_t *cltab = (uint32_t *)(scr + S_HUF + H_CLTAB);
+                    const uint32_t ulane = (uint32_t)lane;
+                    if (lane < 32) clf[lane] = 0;
+                    // HLIT / HDIST: trailing unused symbols are not sent (at least 257 / 1)
+                    uint32_t hlit, hdist;
+                    {
+                        const unsigned long long mh = __ballot(256 + lane < 286 && (lltab[256 + lane] >> 16) != 0);
+                        hlit = 256 + 64 - (uint32_t)__builtin_clzll(mh | 1ull);  // symbol 256 is always used
+                        if (hlit < 257) hlit = 257;
+                        const unsigned long long md = __ballot(lane < 30 && (dtab[lane & 31] >> 16) != 0);
+                        hdist = 64 - (uint32_t)__builtin_clzll(md | 1ull);
+                    }
+                    const uint32_t tot = hlit + hdist;
+                    // code lengths of the concatenated alphabets, 64 per chunk; run starts
+                    uint32_t Lv[5];
+                    unsigned long long St[5];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        const uint32_t i = (uint32_t)c * 64 + ulane;
+                        Lv[c] = i < hlit ? lltab[i] >> 16 : (i < tot ? dtab[(i - hlit) & 31] >> 16 : 0xffu);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        const uint32_t i = (uint32_t)c * 64 + ulane;
+                        const uint32_t pl = c ? rl(Lv[c ? c - 1 : 0], 63) : 0xffffu;  // last of the previous chunk
+                        uint32_t pv = __shfl_up(Lv[c], 1, 64);
+                        if (lane == 0) pv = pl;
+                        St[c] = __ballot(i <= tot && (i == tot || Lv[c] != pv));  // index tot closes the last run
+                    }
+                    // items per run (greedy: 18 for 11..138 zeros, 17 for 3..10, 16 for 3..6 repeats)
+                    uint32_t run[5], cnt[5], off[5];
+                    uint32_t nr = 0;
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        const uint32_t i = (uint32_t)c * 64 + ulane;
+                        const bool start = i < tot && ((St[c] >> ulane) & 1ull);
+                        uint32_t nxt = tot;
+                        {
+                            const unsigned long long above = lane == 63 ? 0ull : (St[c] >> (ulane + 1)) << (ulane + 1);
+                            bool found = false;
+                            if (above) {
+                                nxt = (uint32_t)c * 64 + (uint32_t)__builtin_ctzll(above);
+                                found = true;
+                            }
+#pragma unroll
+                            for (int c2 = c + 1; c2 < 5; ++c2)
+                                if (!found && St[c2]) {
+                                    nxt = (uint32_t)c2 * 64 + (uint32_t)__builtin_ctzll(St[c2]);
+                                    found = true;
+                                }
+                        }
+                        uint32_t r = start ? nxt - i : 0u, n = 0;
+                        if (start) {
+                            if (Lv[c] == 0) {
+                                const uint32_t q = r / 138u, rem = r % 138u;
+                                n = q + (rem >= 3 ? 1u : rem);
+                            } else {
+                                const uint32_t q = (r - 1) / 6u, rem = (r - 1) % 6u;
+                                n = 1 + q + (rem >= 3 ? 1u : rem);
+                            }
+                        }
+                        run[c] = r;
+                        cnt[c] = n;
+                        uint32_t inc = n;
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) {
+                            const uint32_t y = __shfl_up(inc, d, 64);
+                            if (lane >= d) inc += y;
+                        }
+                        off[c] = nr + inc - n;
+                        nr += rl(inc, 63);
+                    }
+                    // write the items, count the code-length symbols
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        if (cnt[c]) {
+                            uint32_t r = run[c], o = off[c];
+                            const uint32_t v = Lv[c];
+                            if (v == 0) {
+                                uint32_t n18 = 0, n17 = 0, n0 = 0;
+                                while (r >= 11) {
+                                    const uint32_t t = r > 138 ? 138 : r;
+                                    rle[o++] = (uint16_t)(18 | ((t - 11) << 8));
+                                    ++n18;
+                                    r -= t;
+                                }
+                                if (r >= 3) {
+                                    rle[o++] = (uint16_t)(17 | ((r - 3) << 8));
+                                    ++n17;
+                                    r = 0;
+                                }
+                                while (r--) {
+                                    rle[o++] = 0;
+                                    ++n0;
+                                }
+                                if (n18) atomicAdd(&clf[18], n18);
+                                if (n17) atomicAdd(&clf[17], n17);
+                                if (n0) atomicAdd(&clf[0], n0);
+                            } else {
+                                uint32_t nv = 1, n16 = 0;
+                                rle[o++] = (uint16_t)v;
+                                --r;
+                                while (r >= 3) {
+                                    const uint32_t t = r > 6 ? 6 : r;
+                                    rle[o++] = (uint16_t)(16 | ((t - 3) << 8));
+                                    ++n16;
+                                    r -= t;
+                                }
+                                while (r--) {
+                                    rle[o++] = (uint16_t)v;
+                                    ++nv;
+                                }
+                                atomicAdd(&clf[v], nv);
+                                if (n16) atomicAdd(&clf[16], n16);
+                            }
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+                    // ---- code-length code (19 symbols, 7 bits) ----
+                    {
+                        uint32_t f = lane < 19 ? clf[lane] : 0u;
+                        const unsigned long long nz = __ballot(f != 0);
+                        if (__builtin_popcountll(nz) < 2 && ulane == ((nz & 1ull) ? 1u : 0u)) f = 1;
+                        uint32_t key = f ? ((f << 9) | ulane) : INF;
+                        key = wave_sort64(key);
+                        const uint32_t mC = (uint32_t)__builtin_popcountll(__ballot(key != INF));
+                        if (lane < 32) TD.sorted[lane] = key;
+                        asm volatile("" ::: "memory");
+                        wave_huffman<1>(TD, mC, 19, 7, cltab);
+                    }
+                    asm volatile("" ::: "memory");
+                    // ---- header bits: every field is OR-merged into the staging words ----
+                    const uint32_t hb = bitpos - base_word * 32;  // bit offset of the header in stage[]
+                    auto put_bits = [&](uint32_t rel, uint32_t v, uint32_t nb) {
+                        // nb <= 17: at most two words
+                        const uint32_t w = rel >> 5, sh = rel & 31;
+                        const uint64_t x = (uint64_t)v << sh;
+                        atomicOr(&stage[w], (uint32_t)x);
+                        if (sh + nb > 32) atomicOr(&stage[w + 1], (uint32_t)(x >> 32));
+                    };
+                    uint32_t hclen;
+                    {
+                        // HCLEN order of the code-length symbols (RFC 1951 3.2.7), order[lane]:
+                        // 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15
+                        const uint64_t oa = 0x0609070800121110ull;  // order[0..7], one byte each
+                        const uint64_t ob = 0x020d030c040b050aull;  // order[8..15]
+                        const uint32_t oc = 0x000f010eu;            // order[16..18]
+                        uint32_t ord = 0;
+                        if (lane < 8)
+                            ord = (uint32_t)(oa >> (8 * ulane)) & 0xffu;
+                        else if (lane < 16)
+                            ord = (uint32_t)(ob >> (8 * (ulane - 8))) & 0xffu;
+                        else if (lane < 19)
+                            ord = (oc >> (8 * (ulane - 16))) & 0xffu;
+                        const uint32_t cll = lane < 19 ? cltab[ord] >> 16 : 0u;
+                        const unsigned long long mu = __ballot(cll != 0);
+                        hclen = 64 - (uint32_t)__builtin_clzll(mu | 1ull);
+                        if (hclen < 4) hclen = 4;
+                        if (lane == 0)
+                            put_bits(hb, bfinal | (2u << 1) | ((hlit - 257) << 3) | ((hdist - 1) << 8) | ((hclen - 4) << 13), 17);
+                        if (ulane < hclen) put_bits(hb + 17 + 3 * ulane, cll, 3);
+                    }
+                    uint32_t pos = hb + 17 + 3 * hclen;
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        const uint32_t t = (uint32_t)c * 64 + ulane;
+                        uint32_t v = 0, nb = 0;
+                        if (t < nr) {
+                            const uint32_t it = rle[t], sym = it & 0xffu, ex = it >> 8;
+                            const uint32_t e = cltab[sym];
+                            v = e & 0xffffu;
+                            nb = e >> 16;
+                            v |= ex << nb;
+                            nb += sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u;
+                        }
+                        uint32_t inc = nb;
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) {
+                            const uint32_t y = __shfl_up(inc, d, 64);
+                            if (lane >= d) inc += y;
+                        }
+                        if (nb) put_bits(pos + inc - nb, v, nb);
+                        pos += rl(inc, 63);
+                    }
+                    if (lane == 0) misc[M_TMP] = pos;
                 }
             } else {
                 // fixed Huffman codes (RFC 1951 3.2.6; FixedHuffmanTable rawdeflate.js:48-68)
