@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "zgpu_dev.h"
+#include "wave_sort.h"
 
 namespace {
 
@@ -232,22 +233,7 @@ __device__ inline void lds_publish(uint32_t *word, uint32_t value) {
     if ((threadIdx.x & 63) == 0) lds_st(word, value);
 }
 
-// bitonic sort of one key per lane across the wave (ascending by lane), in registers
-__device__ inline uint32_t wave_sort64(uint32_t key) {
-    const uint32_t lane = threadIdx.x & 63;
-#pragma unroll
-    for (uint32_t k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            const uint32_t other = __shfl_xor(key, (int)j, 64);
-            const bool up = (lane & k) == 0;
-            const bool lower = (lane & j) == 0;
-            const uint32_t mn = key < other ? key : other, mx = key < other ? other : key;
-            key = (lower == up) ? mn : mx;
-        }
-    }
-    return key;
-}
+using zgpu_sort::wave_sort64;  // one key per lane, ascending by lane, in registers
 
 // RFC 1951 length symbol for l = len-3 (0..255): symbol, extra bit count, extra value
 __device__ inline void len_sym(uint32_t l, uint32_t &sym, uint32_t &eb, uint32_t &ev) {
