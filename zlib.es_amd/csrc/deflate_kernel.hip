@@ -958,12 +958,11 @@ zgpu_deflate_kernel(Params P) {
             // Up to PEND searched items wait per wave until the frontier has passed them
             // (slot 0 is the oldest); then their tokens are emitted.
             int npend = 0;
-            uint32_t q_k[PEND], q_len[PEND], q_dist[PEND];
+            uint32_t q_k[PEND], q_ld[PEND];  // item, best length << 16 | best distance per lane
             // kind / successor of every local index of an item (0 literal, 1 match here,
             // 2 literal + match at +1); no look-ahead across the item boundary
-            auto successor = [&](uint32_t best_len, uint32_t &kind) -> uint32_t {
-                uint32_t l1 = __shfl_down(best_len, 1, 64);
-                if (lane == 63) l1 = 0;
+            auto successor = [&](uint32_t best_len, uint32_t l1, uint32_t &kind) -> uint32_t {
+                // l1: best length of the next position (0 for the item's last lane)
                 uint32_t adv = 1;
                 kind = 0;
                 if (best_len >= 3) {
@@ -981,11 +980,12 @@ zgpu_deflate_kernel(Params P) {
                 return (int32_t)(lds_ld(&misc[M_PARSE]) - k0) > 0;
             };
             auto emit_oldest = [&]() {
-                // ---- tokens of item q_k[0], in registers: lane l <-> local index l ----
-                // five pointer-doubling steps rebuild the jump tables; lane j then follows j
-                // hops from the entry by composing the tables along the bits of j, so the
-                // tokens come out already compacted.
-                const uint32_t k0 = q_k[0], best_len = q_len[0], best_dist = q_dist[0];
+                // ---- tokens of item q_k[0]: lane l <-> local index l ----
+                // The parse path through the item is walked on scalar registers: literal runs
+                // are skipped with a find-first-set over the ballot of match positions, a
+                // match costs one readlane of its successor.  The path mask then gives every
+                // lane its place in the token stream by bit counts; no shuffles.
+                const uint32_t k0 = q_k[0], ld = q_ld[0];
                 const uint32_t p0 = k0 << 6, sl = k0 & (NSLOT - 1);
                 const uint32_t seg_end = (n - p0) < 64u ? (n - p0) : 64u;
                 PH_START();
@@ -995,42 +995,42 @@ zgpu_deflate_kernel(Params P) {
                 }
                 asm volatile("" ::: "memory");
                 PH_END(15);
-                const uint32_t e = slot_entry[sl] - p0;  // local index of the first token
-                const uint32_t tokbase = slot_tokb[sl];
+                // local index of the first token (>= seg_end: a match from before covers the item)
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_entry[sl]) - p0;
+                const uint32_t tokbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_tokb[sl]);
+                uint32_t ldn = __shfl_down(ld, 1, 64);  // the next position's match (lazy tokens)
+                if (lane == 63) ldn = 0;
                 uint32_t kind;
-                uint32_t QJ[6];
-                QJ[0] = successor(best_len, kind);
-#pragma unroll
-                for (int r = 0; r < 5; ++r) {
-                    const uint32_t tj = __shfl(QJ[r], (int)(QJ[r] & 63u), 64);
-                    QJ[r + 1] = QJ[r] < seg_end ? tj : QJ[r];
+                const uint32_t J = successor(ld >> 16, ldn >> 16, kind);
+                const unsigned long long valid = seg_end == 64u ? ~0ull : ((1ull << seg_end) - 1ull);
+                const unsigned long long M = __ballot(kind != 0) & valid;
+                unsigned long long path = 0;
+                for (uint32_t pos = e; pos < seg_end;) {
+                    const unsigned long long rest = M >> pos;
+                    if (!rest) {
+                        path |= ~0ull << pos;
+                        break;
+                    }
+                    const uint32_t d = (uint32_t)__builtin_ctzll(rest);
+                    path |= ((2ull << d) - 1ull) << pos;  // literals pos .. pos+d-1 and the match at pos+d
+                    pos = rl(J, pos + d);
                 }
-                uint32_t Pk = e;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    const uint32_t t2 = __shfl(QJ[r], (int)(Pk & 63u), 64);
-                    if (((lane >> r) & 1) && Pk < seg_end) Pk = t2;
-                }
-                const bool on = Pk < seg_end;
-                const uint32_t tk = (uint32_t)__shfl((int)kind, (int)(Pk & 63u), 64);
-                const int mi = (int)((Pk + (tk == 2 ? 1u : 0u)) & 63u);
-                const uint32_t tl = (uint32_t)__shfl((int)best_len, mi, 64);
-                const uint32_t td = (uint32_t)__shfl((int)best_dist, mi, 64);
-                const uint32_t cnt = on ? (tk == 2 ? 2u : 1u) : 0u;
-                uint32_t inc = cnt;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t y = __shfl_up(inc, d, 64);
-                    if (lane >= d) inc += y;
-                }
+                path &= valid;
+                const unsigned long long two = path & __ballot(kind == 2);
+                const bool on = (path >> lane) & 1ull;
                 if (on) {
-                    uint32_t *dst = tokbuf + tokbase + inc - cnt;
-                    if (tk != 1) {
-                        const uint32_t b = ring[(p0 + Pk) & (RING - 1)];
+                    const uint32_t idx =
+                        __builtin_amdgcn_mbcnt_hi((uint32_t)(path >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)path, 0u)) +
+                        __builtin_amdgcn_mbcnt_hi((uint32_t)(two >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)two, 0u));
+                    uint32_t *dst = tokbuf + tokbase + idx;
+                    if (kind != 1) {
+                        const uint32_t b = ring[(p0 + (uint32_t)lane) & (RING - 1)];
                         *dst++ = b;
                         atomicAdd(&fl[b], 1u);
                     }
-                    if (tk != 0) {
+                    if (kind != 0) {
+                        const uint32_t t = kind == 1 ? ld : ldn;
+                        const uint32_t tl = t >> 16, td = t & 0xffffu;
                         *dst = 0x80000000u | (tl - 3) << 16 | (td - 1);
                         uint32_t sym, eb, ev;
                         len_sym(tl - 3, sym, eb, ev);
@@ -1042,8 +1042,7 @@ zgpu_deflate_kernel(Params P) {
 #pragma unroll
                 for (int i = 0; i + 1 < PEND; ++i) {
                     q_k[i] = q_k[i + 1];
-                    q_len[i] = q_len[i + 1];
-                    q_dist[i] = q_dist[i + 1];
+                    q_ld[i] = q_ld[i + 1];
                 }
                 --npend;
                 PH_END(7);
@@ -1187,7 +1186,9 @@ zgpu_deflate_kernel(Params P) {
                     // ---- exit index and token count of every local index (six doubling steps) ----
                     const uint32_t seg_end = (n - p0) < 64u ? (n - p0) : 64u;
                     uint32_t kind;
-                    uint32_t J = successor(best_len, kind);
+                    uint32_t l1 = __shfl_down(best_len, 1, 64);
+                    if (lane == 63) l1 = 0;
+                    uint32_t J = successor(best_len, l1, kind);
                     if ((uint32_t)lane >= seg_end) J = (uint32_t)lane;  // past the end: stay put
                     uint32_t Cn = (uint32_t)lane < seg_end ? (kind == 2 ? 2u : 1u) : 0u;
 #pragma unroll
@@ -1210,8 +1211,7 @@ zgpu_deflate_kernel(Params P) {
                 for (int i = 0; i < PEND; ++i)
                     if (i == npend) {
                         q_k[i] = k;
-                        q_len[i] = best_len;
-                        q_dist[i] = best_dist;
+                        q_ld[i] = best_len << 16 | best_dist;
                     }
                 ++npend;
                 lds_publish(&slot_done[k & (NSLOT - 1)], k + 1);
