@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import zlib_es_amd as z  # noqa: E402
 
-PHASES = ["load", "blkwait", "iters", "items", "-", "codes+hdr", "emit", "emit-tok", "lag+ld", "sort", "linkwait", "link", "pass1", "pass2", "prep", "parsewait"]
+PHASES = ["load", "blkwait", "ranksort", "trees", "header", "close-rest", "emit", "emit-tok", "lag+ld", "sort", "linkwait", "link", "pass1", "pass2", "prep", "parsewait"]
 
 
 def run(name, data, nu, ub, ctype, lazy):
@@ -37,7 +37,6 @@ def run(name, data, nu, ub, ctype, lazy):
     L.zgpu_prof_read(prof.ctypes.data, 1)
     off, _, _ = plan.fetch()
     nbytes = nu * ub
-    print("  pass1 iterations per item: %.1f ; cycles per iteration: %.0f" % (prof[2] / max(1, prof[3]), prof[12] / max(1, prof[2])))
     per = prof.astype(np.float64) / nbytes
     print("%-8s %7.2f GB/s ratio %.4f | cyc/B: %s | total %.1f" % (
         name, nbytes / dt / 1e9, int(off[-1]) / nbytes,

@@ -52,7 +52,6 @@ constexpr uint32_t REFILL = 16384;  // ring refill granule
 constexpr uint32_t CMP_CAP = 32;   // pass-1 compare length cap (bytes)
 constexpr uint32_t SHARE_MIN = 16;  // matches at least this long offer their distance to the wave
 constexpr int SHARE_ITERS = 6;      // distinct distances scored per wave
-constexpr int STAGE_WORDS = 1792;   // bit staging (>= header + 1024*48/32 + carry)
 
 constexpr uint32_t huf_scratch_bytes(uint32_t cap) { return 17 * cap + 128; }  // see HufS
 
@@ -77,10 +76,14 @@ constexpr uint32_t S_ENT = S_DONE + NSLOT * 4;       // u32[NSLOT]
 constexpr uint32_t S_TOKB = S_ENT + NSLOT * 4;       // u32[NSLOT]
 static_assert(S_TOKB + NSLOT * 4 <= SCR_BYTES, "item-loop scratch");
 // scratch, block close phase
-constexpr uint32_t S_STAGE = 0;                        // u32[STAGE_WORDS]
-constexpr uint32_t S_LLTAB = S_STAGE + STAGE_WORDS * 4;  // u32[288] code | len<<16
+constexpr uint32_t S_LLTAB = 0;                          // u32[288] code | len<<16
 constexpr uint32_t S_DTAB = S_LLTAB + 288 * 4;           // u32[32]
-constexpr uint32_t S_HUF = S_DTAB + 32 * 4;              // Huffman build scratch
+constexpr uint32_t S_STAGE = S_DTAB + 32 * 4;            // u32[STAGE_WORDS] bit staging
+constexpr int STAGE_WORDS = (SCR_BYTES - S_STAGE) / 4;   // >= header + 2 * 1024 * 48 / 32 + carry
+static_assert(STAGE_WORDS >= 160 + 2 * 1024 * 48 / 32 + 2, "staging capacity");
+// The Huffman build scratch overlays the tail of the staging words: the header
+// (the only bits staged while the trees are built) stays below it.
+constexpr uint32_t S_HUF = S_STAGE + 7168;
 constexpr uint32_t HUF_BYTES = SCR_BYTES - S_HUF;
 // Huffman build scratch map (bytes from S_HUF): the lit/len tree, then the
 // distance tree (reused for the code-length tree); once the lit/len and
@@ -326,13 +329,15 @@ __device__ void wave_huffman(const HufS &S, uint32_t m_in, uint32_t nsym, uint32
     for (uint32_t sy = lane; sy < nsym; sy += 64) S.lens[sy] = 0;
     if (lane < 32) S.blc[lane] = 0;
     // ---- two-queue merge.  Leaves and internal nodes are each consumed in order, so a
-    // 64-entry register window per queue (refilled from LDS every 64 entries) feeds the
-    // heads through readlane; node k's weight goes to LDS and, when it falls into the
-    // current window, into the window register as well.
+    // 64-entry register window per queue feeds the heads through readlane.  Produced
+    // nodes collect in a window register that is flushed to LDS every 64 nodes (with the
+    // count of leaves consumed so far, from which the parents follow); the node queue
+    // reads that register while it consumes from the window being produced.
     {
         uint32_t li = 0, ii = 0;
-        uint32_t lwin = lane < m ? S.sorted[lane] >> 9 : INF;
-        uint32_t nwin = INF;
+        uint32_t lwin = lane < m ? S.sorted[lane] >> 9 : INF;  // leaves [li & ~63, +64)
+        uint32_t nwin = INF;                                   // nodes  [ii & ~63, +64), once flushed
+        uint32_t pwin = INF, cwin = 0;                         // nodes / leaf counts [k & ~63, +64)
         uint32_t lhead = rl(lwin, 0), nhead = INF;
         for (uint32_t k = 0; k + 1 < m; ++k) {
             uint32_t w = 0;
@@ -346,17 +351,26 @@ __device__ void wave_huffman(const HufS &S, uint32_t m_in, uint32_t nsym, uint32
                 } else {
                     w += nhead;
                     ++ii;
-                    if ((ii & 63u) == 0) nwin = ii + lane < k ? S.niw[ii + lane] : INF;
-                    nhead = rl(nwin, ii & 63u);
+                    // nodes at or beyond k do not exist yet: the production window holds INF there
+                    if ((ii >> 6) == (k >> 6)) {
+                        nhead = rl(pwin, ii & 63u);
+                    } else {
+                        if ((ii & 63u) == 0) nwin = S.niw[ii + lane];
+                        nhead = rl(nwin, ii & 63u);
+                    }
                 }
             }
-            if (lane == 0) {
-                S.niw[k] = w;
-                S.cl[k] = (uint16_t)li;
-            }
-            if ((k >> 6) == (ii >> 6)) {
-                nwin = wl(nwin, w, k & 63u);
-                if (ii == k) nhead = w;
+            pwin = wl(pwin, w, k & 63u);
+            cwin = wl(cwin, li, k & 63u);
+            if (ii == k) nhead = w;
+            if ((k & 63u) == 63u || k + 2 == m) {
+                const uint32_t kb = k & ~63u;
+                if (kb + lane <= k) {
+                    S.niw[kb + lane] = pwin;
+                    S.cl[kb + lane] = (uint16_t)cwin;
+                }
+                if ((ii >> 6) == (k >> 6)) nwin = pwin;  // the node queue is still inside this window
+                pwin = INF;
             }
         }
     }
@@ -623,9 +637,11 @@ zgpu_deflate_kernel(Params P) {
                 }
                 if (mykey != INF) (tid < 288 ? TL.sorted : TD.sorted)[myrank] = mykey;
                 __syncthreads();
+                PH_END(2);
                 // ---- the two trees, one wave each ----
                 if (wave == 0) wave_huffman<5>(TL, mL, 286, 15, lltab);
                 if (wave == 1) wave_huffman<1>(TD, mD, 30, 15, dtab);
+                PH_END(3);
                 __syncthreads();
                 // ---- header (wave 0): HLIT/HDIST, run-length items, code-length code, bits ----
                 if (wave == 0) {
@@ -816,6 +832,7 @@ zgpu_deflate_kernel(Params P) {
                         pos += rl(inc, 63);
                     }
                     if (lane == 0) misc[M_TMP] = pos;
+                    PH_END(4);
                 }
             } else {
                 // fixed Huffman codes (RFC 1951 3.2.6; FixedHuffmanTable rawdeflate.js:48-68)
@@ -848,59 +865,74 @@ zgpu_deflate_kernel(Params P) {
             const uint32_t ntok = misc[M_NTOK];
             __syncthreads();
             PH_END(5);
-            // ---- emit tokens ----
-            for (uint32_t t0 = 0; t0 < ntok; t0 += WG) {
-                uint64_t bits = 0;
-                uint32_t nb = 0;
-                if (t0 + tid < ntok) {
-                    const uint32_t tk = tokbuf[t0 + tid];
-                    if (!(tk & 0x80000000u)) {
-                        const uint32_t e = lltab[tk];
-                        bits = e & 0xffff;
-                        nb = e >> 16;
-                    } else {
-                        uint32_t sym, eb, ev;
-                        len_sym((tk >> 16) & 0xff, sym, eb, ev);
-                        uint32_t e = lltab[sym];
-                        bits = e & 0xffff;
-                        nb = e >> 16;
-                        bits |= (uint64_t)ev << nb;
-                        nb += eb;
-                        dist_sym(tk & 0xffff, sym, eb, ev);
-                        e = dtab[sym];
-                        bits |= (uint64_t)(e & 0xffff) << nb;
-                        nb += e >> 16;
-                        bits |= (uint64_t)ev << nb;
-                        nb += eb;
-                    }
+            // ---- emit tokens: two per thread and pass ----
+            // bits of a pass are OR-merged into the staging words at their prefix-sum
+            // offsets; full words leave with coalesced stores and are cleared by the
+            // thread that stored them, the partial last word moves to the front.
+            for (int i = (S_HUF - S_STAGE) / 4 + tid; i < STAGE_WORDS; i += WG) stage[i] = 0;  // held the tree scratch
+            auto tok_bits = [&](uint32_t tk, uint64_t &bits, uint32_t &nb) {
+                if (!(tk & 0x80000000u)) {
+                    const uint32_t e = lltab[tk];
+                    bits = e & 0xffff;
+                    nb = e >> 16;
+                } else {
+                    uint32_t sym, eb, ev;
+                    len_sym((tk >> 16) & 0xff, sym, eb, ev);
+                    uint32_t e = lltab[sym];
+                    bits = e & 0xffff;
+                    nb = e >> 16;
+                    bits |= (uint64_t)ev << nb;
+                    nb += eb;
+                    dist_sym(tk & 0xffff, sym, eb, ev);
+                    e = dtab[sym];
+                    bits |= (uint64_t)(e & 0xffff) << nb;
+                    nb += e >> 16;
+                    bits |= (uint64_t)ev << nb;
+                    nb += eb;
+                }
+            };
+            auto stage_or = [&](uint32_t rel, uint64_t bits, uint32_t nb) {
+                if (!nb) return;
+                const uint32_t w = rel >> 5, sh = rel & 31;
+                const uint64_t lo = bits << sh;
+                atomicOr(&stage[w], (uint32_t)lo);
+                if ((uint32_t)(lo >> 32)) atomicOr(&stage[w + 1], (uint32_t)(lo >> 32));
+                if (sh && (nb + sh > 64)) atomicOr(&stage[w + 2], (uint32_t)(bits >> (64 - sh)));
+            };
+            for (uint32_t t0 = 0; t0 < ntok; t0 += 2 * WG) {
+                uint64_t b0 = 0, b1 = 0;
+                uint32_t n0 = 0, n1 = 0;
+                const uint32_t ti = t0 + 2 * (uint32_t)tid;
+                if (ti < ntok) {
+                    const uint2 tk = *(const uint2 *)(tokbuf + ti);  // ti is even; the buffer has slack past ntok
+                    tok_bits(tk.x, b0, n0);
+                    if (ti + 1 < ntok) tok_bits(tk.y, b1, n1);
                 }
                 uint32_t total;
-                const uint32_t off = block_scan_excl(nb, &total, misc + M_SCAN);
-                if (nb) {
-                    const uint32_t rel = bitpos + off - base_word * 32;
-                    const uint32_t w = rel >> 5, sh = rel & 31;
-                    const uint64_t lo = bits << sh;
-                    atomicOr(&stage[w], (uint32_t)lo);
-                    if ((uint32_t)(lo >> 32)) atomicOr(&stage[w + 1], (uint32_t)(lo >> 32));
-                    if (sh && (nb + sh > 64)) atomicOr(&stage[w + 2], (uint32_t)(bits >> (64 - sh)));
-                }
+                const uint32_t off = block_scan_excl(n0 + n1, &total, misc + M_SCAN);
+                const uint32_t rel = bitpos + off - base_word * 32;
+                stage_or(rel, b0, n0);
+                stage_or(rel + n0, b1, n1);
                 __syncthreads();
                 bitpos += total;
                 const uint32_t full = (bitpos >> 5) - base_word;
-                const bool fits = base_word + full <= cap_words;
-                if (fits)
-                    for (uint32_t i = tid; i < full; i += WG) out32[base_word + i] = stage[i];
-                else if (tid == 0)
-                    misc[M_OVF] = 1;
-                __syncthreads();
-                const uint32_t cw = stage[full];
-                __syncthreads();
-                for (uint32_t i = tid; i <= full + 2 && i < (uint32_t)STAGE_WORDS; i += WG) stage[i] = 0;
-                __syncthreads();
-                if (tid == 0) stage[0] = cw;
+                if (base_word + full <= cap_words) {
+                    for (uint32_t i = tid; i < full; i += WG) {
+                        out32[base_word + i] = stage[i];
+                        stage[i] = 0;
+                    }
+                } else {
+                    for (uint32_t i = tid; i < full; i += WG) stage[i] = 0;
+                    if (tid == 0) misc[M_OVF] = 1;
+                }
+                if (tid == 0 && full) {
+                    stage[0] = stage[full];
+                    stage[full] = 0;
+                }
                 base_word += full;
-                __syncthreads();
+                // the two barriers of the next pass's prefix sum separate this from its ORs
             }
+            __syncthreads();
             PH_END(6);
             carry_word = stage[0];
             __syncthreads();
@@ -1075,9 +1107,6 @@ zgpu_deflate_kernel(Params P) {
                     if (need > n) need = n;
                     lds_wait_ge(&misc[M_LOADED], need);
                 }
-#ifdef ZGPU_PROFILE
-                if (tid == 0) ph_acc[3]++;
-#endif
                 PH_END(8);
                 // ---- insert: sort (hash, lane) in registers, link chains in item order ----
                 uint32_t key = 0xffffffffu;
