@@ -113,9 +113,15 @@ const uint32_t *zgpu_plan_adler_device(const zgpu_plan *plan);
  * returns ZGPU_E_UNIT if any unit reported overflow. */
 int zgpu_plan_fetch(zgpu_plan *plan, uint64_t *out_off, uint32_t *crc32, uint32_t *adler32,
                     void *stream);
-/* Average device time of the last run's DEFLATE kernel in milliseconds,
- * measured with HIP events on the run's stream (waits for it). */
+/* Device time of the last run in milliseconds, measured with HIP events on the
+ * run's stream (waits for it): deflate_ms covers the search and emit kernels
+ * (or the stored-block kernel), total_ms the whole run. */
 int zgpu_plan_kernel_ms(zgpu_plan *plan, float *deflate_ms, float *total_ms);
+/* The same split by kernel: the search kernel (lz77 + searchLongestMatch_,
+ * src/rawdeflate.js:283-395) and the emit kernel (Huffman codes, header and
+ * bits, :176-277,:474-605).  Timed on the first round of units; emit_ms is 0
+ * when the plan needed more than one round of token scratch. */
+int zgpu_plan_phase_ms(zgpu_plan *plan, float *search_ms, float *emit_ms);
 
 /* ---- checksums ----------------------------------------------------------
  * zgpu_checksum replaces CRC32.calc(data) (src/crc32.js:14-16,25-42) and

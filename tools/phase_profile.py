@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import zlib_es_amd as z  # noqa: E402
 
-PHASES = ["load", "blkwait", "ranksort", "trees", "header", "close-rest", "emit", "emit-tok", "lag+ld", "sort", "linkwait", "link", "pass1", "pass2", "prep", "parsewait"]
+PHASES = ["load", "blkwait", "-", "-", "-", "-", "-", "emit-tok", "lag+ld", "sort", "linkwait", "link", "pass1", "pass2", "prep", "parsewait"]
 
 
 def run(name, data, nu, ub, ctype, lazy):
@@ -38,8 +38,9 @@ def run(name, data, nu, ub, ctype, lazy):
     off, _, _ = plan.fetch()
     nbytes = nu * ub
     per = prof.astype(np.float64) / nbytes
-    print("%-8s %7.2f GB/s ratio %.4f | cyc/B: %s | total %.1f" % (
-        name, nbytes / dt / 1e9, int(off[-1]) / nbytes,
+    sm, em = plan.phase_ms()
+    print("%-8s %7.2f GB/s (search %.2f ms, emit %.2f ms) ratio %.4f | search cyc/B: %s | total %.1f" % (
+        name, nbytes / dt / 1e9, sm, em, int(off[-1]) / nbytes,
         " ".join("%s=%.1f" % (p, v) for p, v in zip(PHASES, per) if p != "-"), per.sum()), flush=True)
 
 

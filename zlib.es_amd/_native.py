@@ -21,7 +21,7 @@ SYMBOLS = [
     "zgpu_set_min_lazy",
     "zgpu_deflate_bound", "zgpu_deflate_batch", "zgpu_plan_create", "zgpu_plan_destroy",
     "zgpu_plan_out_bound", "zgpu_plan_run", "zgpu_plan_out_off_device", "zgpu_plan_crc_device",
-    "zgpu_plan_adler_device", "zgpu_plan_fetch", "zgpu_plan_kernel_ms", "zgpu_checksum",
+    "zgpu_plan_adler_device", "zgpu_plan_fetch", "zgpu_plan_kernel_ms", "zgpu_plan_phase_ms", "zgpu_checksum",
     "zgpu_checksum_device", "zgpu_crc32_update", "zgpu_adler32_update", "zgpu_checksum_kernel_ms",
     "zgpu_crc32_combine", "zgpu_adler32_combine",
 ]
@@ -76,6 +76,8 @@ def lib():
     L.zgpu_plan_fetch.argtypes = [vp, vp, vp, vp, vp]
     L.zgpu_plan_kernel_ms.restype = i32
     L.zgpu_plan_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.zgpu_plan_phase_ms.restype = i32
+    L.zgpu_plan_phase_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.zgpu_checksum.restype = i32
     L.zgpu_checksum.argtypes = [vp, u64, C.POINTER(u32), C.POINTER(u32)]
     L.zgpu_checksum_device.restype = i32
@@ -216,6 +218,12 @@ class Plan:
     def kernel_ms(self):
         a, b = C.c_float(0), C.c_float(0)
         _check(lib().zgpu_plan_kernel_ms(self._h, C.byref(a), C.byref(b)), "zgpu_plan_kernel_ms")
+        return a.value, b.value
+
+    def phase_ms(self):
+        """(search kernel ms, emit kernel ms) of the last run's first round"""
+        a, b = C.c_float(0), C.c_float(0)
+        _check(lib().zgpu_plan_phase_ms(self._h, C.byref(a), C.byref(b)), "zgpu_plan_phase_ms")
         return a.value, b.value
 
     def out_off_device(self):

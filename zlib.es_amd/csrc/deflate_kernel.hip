@@ -55,37 +55,36 @@ constexpr int SHARE_ITERS = 6;      // distinct distances scored per wave
 
 constexpr uint32_t huf_scratch_bytes(uint32_t cap) { return 17 * cap + 128; }  // see HufS
 
-// ---- LDS map (bytes) -------------------------------------------------------
+// ---- LDS map of the search kernel (bytes) ------------------------------------
 constexpr uint32_t L_RING = 0;
 constexpr uint32_t L_PREV = L_RING + RING + RING_PAD;      // u16[32768]
 constexpr uint32_t L_HEAD = L_PREV + 65536;                // u16[1<<HBITS]
 constexpr uint32_t L_FL = L_HEAD + (2u << HBITS);          // u32[288] lit/len freqs
 constexpr uint32_t L_FD = L_FL + 288 * 4;                  // u32[32]  dist freqs
-constexpr uint32_t L_MISC = L_FD + 32 * 4;                 // u32[64]  scan partials, control
-constexpr uint32_t L_SCR = L_MISC + 64 * 4;                // phase scratch
-constexpr uint32_t SCR_BYTES = 14336;
-constexpr uint32_t L_TOTAL = L_SCR + SCR_BYTES;
-static_assert(L_TOTAL <= 163840, "LDS budget");
-
-// scratch, item loop (parse bookkeeping of in-flight items)
+constexpr uint32_t L_MISC = L_FD + 32 * 4;                 // u32[64]  control words
+constexpr uint32_t L_SCR = L_MISC + 64 * 4;                // parse bookkeeping of in-flight items
 constexpr uint32_t NSLOT = 64;                       // > LAG
 constexpr uint32_t S_EXIT = 0;                       // u16[NSLOT*64]
 constexpr uint32_t S_CNT = S_EXIT + NSLOT * 64 * 2;  // u8[NSLOT*64]
 constexpr uint32_t S_DONE = S_CNT + NSLOT * 64;      // u32[NSLOT]
 constexpr uint32_t S_ENT = S_DONE + NSLOT * 4;       // u32[NSLOT]
 constexpr uint32_t S_TOKB = S_ENT + NSLOT * 4;       // u32[NSLOT]
-static_assert(S_TOKB + NSLOT * 4 <= SCR_BYTES, "item-loop scratch");
-// scratch, block close phase
-constexpr uint32_t S_LLTAB = 0;                          // u32[288] code | len<<16
-constexpr uint32_t S_DTAB = S_LLTAB + 288 * 4;           // u32[32]
-constexpr uint32_t S_STAGE = S_DTAB + 32 * 4;            // u32[STAGE_WORDS] bit staging
-constexpr int STAGE_WORDS = (SCR_BYTES - S_STAGE) / 4;   // >= header + 2 * 1024 * 48 / 32 + carry
-static_assert(STAGE_WORDS >= 160 + 2 * 1024 * 48 / 32 + 2, "staging capacity");
-// The Huffman build scratch overlays the tail of the staging words: the header
-// (the only bits staged while the trees are built) stays below it.
-constexpr uint32_t S_HUF = S_STAGE + 7168;
-constexpr uint32_t HUF_BYTES = SCR_BYTES - S_HUF;
-// Huffman build scratch map (bytes from S_HUF): the lit/len tree, then the
+constexpr uint32_t SCR_BYTES = S_TOKB + NSLOT * 4;
+constexpr uint32_t L_TOTAL = L_SCR + SCR_BYTES;
+static_assert(L_TOTAL <= 163840, "LDS budget");
+
+// ---- LDS map of the emit kernel (bytes) --------------------------------------
+constexpr int EWG = 256;            // threads of an emit workgroup
+constexpr int ETOK = 2 * EWG;       // tokens per emission pass
+constexpr uint32_t E_FL = 0;                        // u32[288] + u32[32] block histograms
+constexpr uint32_t E_MISC = E_FL + 320 * 4;         // u32[64]
+constexpr uint32_t E_LLTAB = E_MISC + 64 * 4;       // u32[288] code | len<<16
+constexpr uint32_t E_DTAB = E_LLTAB + 288 * 4;      // u32[32]
+constexpr uint32_t E_STAGE = E_DTAB + 32 * 4;       // u32[STAGE_WORDS] bit staging
+constexpr int STAGE_WORDS = 1024;                   // >= header + ETOK * 48 / 32 + carry
+static_assert(STAGE_WORDS >= 160 + ETOK * 48 / 32 + 2, "staging capacity");
+constexpr uint32_t E_HUF = E_STAGE + STAGE_WORDS * 4;  // Huffman build scratch
+// Huffman build scratch map (bytes from E_HUF): the lit/len tree, then the
 // distance tree (reused for the code-length tree); once the lit/len and
 // distance codes exist, the run-length items of the header reuse the first.
 constexpr uint32_t H_TL = 0;
@@ -94,9 +93,9 @@ constexpr uint32_t H_END = H_TD + huf_scratch_bytes(32);
 constexpr uint32_t H_RLE = 0;      // u16[320] items: symbol | extra << 8
 constexpr uint32_t H_CLF = 640;    // u32[32] code-length symbol freqs
 constexpr uint32_t H_CLTAB = 768;  // u32[32]
-static_assert(H_END <= HUF_BYTES, "huffman scratch");
+constexpr uint32_t E_TOTAL = E_HUF + H_END;
 
-// misc words
+// misc words (search kernel: M_UNIT, M_NTOK, M_ITEM..; emit kernel: M_SCAN, M_UNIT, M_NTOK, M_TMP, M_OVF)
 enum { M_SCAN = 0 /*[16]*/, M_UNIT = 32, M_NTOK = 34, M_TMP = 35, M_OVF = 36,
        M_ITEM = 40,    // next item to hand out
        M_LINK = 41,    // item whose turn it is to link its hash chains
@@ -169,6 +168,7 @@ __device__ inline uint32_t hash3(uint32_t w) {
 
 // exclusive prefix sum over the workgroup; returns this thread's offset and
 // the total through *total.  Uses misc[M_SCAN..+16].  Two barriers.
+template <int NW>
 __device__ inline uint32_t block_scan_excl(uint32_t v, uint32_t *total, uint32_t *part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t x = v;
@@ -181,7 +181,7 @@ __device__ inline uint32_t block_scan_excl(uint32_t v, uint32_t *total, uint32_t
     __syncthreads();
     uint32_t wsum = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < WG / 64; ++w) {
+    for (int w = 0; w < NW; ++w) {
         uint32_t p = part[w];
         if (w < wave) wsum += p;
         tot += p;
@@ -490,19 +490,19 @@ __device__ void wave_huffman(const HufS &S, uint32_t m_in, uint32_t nsym, uint32
     }
 }
 
+// ---- search kernel ----------------------------------------------------------
 struct Params {
     const uint8_t *in;
-    const uint64_t *in_off;    // n_units+1
-    const uint64_t *slot_off;  // n_units+1, 16-byte aligned slots in out_tmp
-    uint8_t *out_tmp;
-    uint32_t *out_size;  // n_units
-    uint32_t *status;    // n_units
-    uint32_t *tok;       // gridDim.x * TOK_CAP
-    uint32_t *counter;   // unit queue head
-    uint32_t n_units;
-    int ctype, lazy, max_chain, nice;
-    uint32_t flags;
-    unsigned long long *prof;  // 16 phase counters (diagnostic builds) or null
+    const uint64_t *in_off;     // n_units+1
+    uint32_t *tok;              // token buffer of this round
+    const uint64_t *tok_off;    // n_units: first token of the unit within tok
+    const uint32_t *blk_first;  // n_units: index of the unit's first block
+    uint32_t *hist;             // blocks x 320 symbol counts (lit/len 288, dist 32)
+    uint32_t *ntok;             // blocks: tokens incl. end-of-block
+    uint32_t *counter;          // unit queue head (relative to unit_first)
+    uint32_t unit_first, unit_end;
+    int lazy, max_chain, nice;
+    unsigned long long *prof;   // 16 phase counters (diagnostic builds) or null
 };
 
 }  // namespace
@@ -511,37 +511,29 @@ extern "C" __global__ void __launch_bounds__(WG)
 zgpu_deflate_kernel(Params P) {
     __shared__ __align__(16) uint8_t lds_raw[L_TOTAL];
     Lds L{lds_raw};
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     uint8_t *ring = L.ring();
     uint16_t *prevt = L.prev();
     uint16_t *head = L.head();
     uint32_t *fl = L.fl(), *fd = L.fd(), *misc = L.misc();
     uint8_t *scr = L.scr();
-    uint32_t *tokbuf = P.tok + (size_t)blockIdx.x * ZGPU_TOK_CAP;
     PH_DECL;
 
     for (;;) {
-        if (tid == 0) misc[M_UNIT] = atomicAdd(P.counter, 1u);
+        if (tid == 0) misc[M_UNIT] = P.unit_first + atomicAdd(P.counter, 1u);
         __syncthreads();
         const uint32_t u = misc[M_UNIT];
         __syncthreads();
-        if (u >= P.n_units) break;
+        if (u >= P.unit_end) break;
 
         const uint8_t *in = P.in + P.in_off[u];
         const uint32_t n = (uint32_t)(P.in_off[u + 1] - P.in_off[u]);
-        uint32_t *out32 = (uint32_t *)(P.out_tmp + P.slot_off[u]);
-        const uint32_t cap_words = (uint32_t)((P.slot_off[u + 1] - P.slot_off[u]) >> 2);
-        const bool final_unit =
-            (P.flags & 1u) || ((P.flags & 4u) && u == P.n_units - 1) || !(P.flags & 2u);
-        const bool sync_unit = !final_unit;
+        uint32_t *tokbuf = P.tok + P.tok_off[u];  // of the block in progress
 
         // ---- unit init ----
         for (int i = tid; i < (1 << HBITS) / 8; i += WG)
             ((uint4 *)head)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
         for (int i = tid; i < 320; i += WG) fl[i] = 0;  // fl[288] + fd[32] are adjacent
-        uint32_t bitpos = 0;      // bits emitted so far in this unit (uniform)
-        uint32_t base_word = 0;   // output word index of stage[0] (uniform)
-        uint32_t carry_word = 0;  // partial word carried between blocks (uniform)
         const uint32_t nitems = (n + 63) >> 6;  // items of 64 positions
         const bool aligned = (((uintptr_t)in) & 15u) == 0;
         PH_START();
@@ -555,400 +547,38 @@ zgpu_deflate_kernel(Params P) {
                 misc[M_PARSE] = 0;
                 misc[M_ENTRY] = 0;
                 misc[M_NTOK] = 0;
-                misc[M_OVF] = 0;
                 misc[M_LOADED] = hi;
                 misc[M_LOCK] = 0;
             }
+            // stamps of the previous unit's items must not be taken for this unit's
+            if (tid < (int)NSLOT) ((uint32_t *)(scr + S_DONE))[tid] = 0;
         }
         __syncthreads();
         PH_END(0);
 
-        // ---- close a DEFLATE block (all threads; uniform) ----
-        auto close_block = [&](const bool last_block) {
-            PH_START();
-            // ---- close a DEFLATE block ----
-            const uint32_t bfinal = (last_block && final_unit) ? 1u : 0u;
-            uint32_t *stage = (uint32_t *)(scr + S_STAGE);
-            uint32_t *lltab = (uint32_t *)(scr + S_LLTAB);
-            uint32_t *dtab = (uint32_t *)(scr + S_DTAB);
-            __syncthreads();
+        // ---- a block is done: end-of-block token, token count and histograms to global
+        // memory for the emit kernel; the block state starts over ----
+        auto flush_block = [&](uint32_t blk) {
+            const uint32_t gb = P.blk_first[u] + blk;
             if (tid == 0) {
-                tokbuf[misc[M_NTOK]++] = 256;  // end of block
-                fl[256]++;
+                const uint32_t nt = misc[M_NTOK];
+                tokbuf[nt] = 256;
+                P.ntok[gb] = nt + 1;
+                misc[M_NTOK] = 0;
             }
-            for (int i = tid; i < STAGE_WORDS; i += WG) stage[i] = 0;
-            __syncthreads();
-            if (tid == 0) stage[0] = carry_word;
-            BitW bw{stage, bitpos - base_word * 32};
-            if (P.ctype == 2) {
-                const HufS TL = huf_scratch(scr + S_HUF + H_TL, 288), TD = huf_scratch(scr + S_HUF + H_TD, 32);
-                const uint32_t INF = 0xffffffffu;
-                // every code set gets at least two symbols, so it is complete: a block that
-                // holds only the end-of-block symbol gains literal 0, and the distance
-                // alphabet is topped up to two used symbols
-                if (tid == 0 && misc[M_NTOK] < 2) fl[0] = 1;
-                if (wave == 1) {
-                    const unsigned long long nz = __ballot(lane < 30 && fd[lane] != 0);
-                    const int c = __builtin_popcountll(nz);
-                    if (c < 2 && lane == 0) {
-                        if (c == 0) fd[0] = 1;
-                        fd[(c == 0 || (nz & 1ull)) ? 1 : 0] = 1;
-                    }
-                }
-                __syncthreads();
-                // ---- sort keys (weight << 9 | symbol, unused = INF) and rank sort ----
-                if (tid < 288) {
-                    TL.niw[tid] = (tid < 286 && fl[tid]) ? ((fl[tid] << 9) | (uint32_t)tid) : INF;
-                    TL.rank[tid] = 0;
-                } else if (tid < 320) {
-                    const int d = tid - 288;
-                    TD.niw[d] = (d < 30 && fd[d]) ? ((fd[d] << 9) | (uint32_t)d) : INF;
-                }
-                __syncthreads();
-                if (tid < 864) {
-                    // three threads per lit/len key, each counting the smaller keys in a third
-                    const int i = tid % 288, part = tid / 288;
-                    const uint32_t me = TL.niw[i];
-                    const uint4 *kp = (const uint4 *)(TL.niw + part * 96);
-                    uint32_t cnt = 0;
-#pragma unroll 4
-                    for (int j = 0; j < 24; ++j) {
-                        const uint4 q = kp[j];
-                        cnt += (q.x < me) + (q.y < me) + (q.z < me) + (q.w < me);
-                    }
-                    atomicAdd(&TL.rank[i], cnt);
-                } else if (tid < 896) {
-                    const int d = tid - 864;
-                    const uint32_t me = TD.niw[d];
-                    uint32_t cnt = 0;
-                    for (int j = 0; j < 32; ++j) cnt += TD.niw[j] < me;
-                    TD.rank[d] = cnt;
-                }
-                __syncthreads();
-                // a padding key's rank is the number of used symbols
-                const uint32_t mL = TL.rank[287], mD = TD.rank[31];
-                uint32_t myrank = 0, mykey = INF;
-                if (tid < 288) {
-                    myrank = TL.rank[tid];
-                    mykey = TL.niw[tid];
-                } else if (tid < 320) {
-                    myrank = TD.rank[tid - 288];
-                    mykey = TD.niw[tid - 288];
-                }
-                if (mykey != INF) (tid < 288 ? TL.sorted : TD.sorted)[myrank] = mykey;
-                __syncthreads();
-                PH_END(2);
-                // ---- the two trees, one wave each ----
-                if (wave == 0) wave_huffman<5>(TL, mL, 286, 15, lltab);
-                if (wave == 1) wave_huffman<1>(TD, mD, 30, 15, dtab);
-                PH_END(3);
-                __syncthreads();
-                // ---- header (wave 0): HLIT/HDIST, run-length items, code-length code, bits ----
-                if (wave == 0) {
-                    uint16_t *rle = (uint16_t *)(scr + S_HUF + H_RLE);
-                    uint32_t *clf = (uint32_t *)(scr + S_HUF + H_CLF);
-                    uint32_t *cltab = (uint32_t *)(scr + S_HUF + H_CLTAB);
-                    const uint32_t ulane = (uint32_t)lane;
-                    if (lane < 32) clf[lane] = 0;
-                    // HLIT / HDIST: trailing unused symbols are not sent (at least 257 / 1)
-                    uint32_t hlit, hdist;
-                    {
-                        const unsigned long long mh = __ballot(256 + lane < 286 && (lltab[256 + lane] >> 16) != 0);
-                        hlit = 256 + 64 - (uint32_t)__builtin_clzll(mh | 1ull);  // symbol 256 is always used
-                        if (hlit < 257) hlit = 257;
-                        const unsigned long long md = __ballot(lane < 30 && (dtab[lane & 31] >> 16) != 0);
-                        hdist = 64 - (uint32_t)__builtin_clzll(md | 1ull);
-                    }
-                    const uint32_t tot = hlit + hdist;
-                    // code lengths of the concatenated alphabets, 64 per chunk; run starts
-                    uint32_t Lv[5];
-                    unsigned long long St[5];
-#pragma unroll
-                    for (int c = 0; c < 5; ++c) {
-                        const uint32_t i = (uint32_t)c * 64 + ulane;
-                        Lv[c] = i < hlit ? lltab[i] >> 16 : (i < tot ? dtab[(i - hlit) & 31] >> 16 : 0xffu);
-                    }
-#pragma unroll
-                    for (int c = 0; c < 5; ++c) {
-                        const uint32_t i = (uint32_t)c * 64 + ulane;
-                        const uint32_t pl = c ? rl(Lv[c ? c - 1 : 0], 63) : 0xffffu;  // last of the previous chunk
-                        uint32_t pv = __shfl_up(Lv[c], 1, 64);
-                        if (lane == 0) pv = pl;
-                        St[c] = __ballot(i <= tot && (i == tot || Lv[c] != pv));  // index tot closes the last run
-                    }
-                    // items per run (greedy: 18 for 11..138 zeros, 17 for 3..10, 16 for 3..6 repeats)
-                    uint32_t run[5], cnt[5], off[5];
-                    uint32_t nr = 0;
-#pragma unroll
-                    for (int c = 0; c < 5; ++c) {
-                        const uint32_t i = (uint32_t)c * 64 + ulane;
-                        const bool start = i < tot && ((St[c] >> ulane) & 1ull);
-                        uint32_t nxt = tot;
-                        {
-                            const unsigned long long above = lane == 63 ? 0ull : (St[c] >> (ulane + 1)) << (ulane + 1);
-                            bool found = false;
-                            if (above) {
-                                nxt = (uint32_t)c * 64 + (uint32_t)__builtin_ctzll(above);
-                                found = true;
-                            }
-#pragma unroll
-                            for (int c2 = c + 1; c2 < 5; ++c2)
-                                if (!found && St[c2]) {
-                                    nxt = (uint32_t)c2 * 64 + (uint32_t)__builtin_ctzll(St[c2]);
-                                    found = true;
-                                }
-                        }
-                        uint32_t r = start ? nxt - i : 0u, n = 0;
-                        if (start) {
-                            if (Lv[c] == 0) {
-                                const uint32_t q = r / 138u, rem = r % 138u;
-                                n = q + (rem >= 3 ? 1u : rem);
-                            } else {
-                                const uint32_t q = (r - 1) / 6u, rem = (r - 1) % 6u;
-                                n = 1 + q + (rem >= 3 ? 1u : rem);
-                            }
-                        }
-                        run[c] = r;
-                        cnt[c] = n;
-                        uint32_t inc = n;
-#pragma unroll
-                        for (int d = 1; d < 64; d <<= 1) {
-                            const uint32_t y = __shfl_up(inc, d, 64);
-                            if (lane >= d) inc += y;
-                        }
-                        off[c] = nr + inc - n;
-                        nr += rl(inc, 63);
-                    }
-                    // write the items, count the code-length symbols
-#pragma unroll
-                    for (int c = 0; c < 5; ++c) {
-                        if (cnt[c]) {
-                            uint32_t r = run[c], o = off[c];
-                            const uint32_t v = Lv[c];
-                            if (v == 0) {
-                                uint32_t n18 = 0, n17 = 0, n0 = 0;
-                                while (r >= 11) {
-                                    const uint32_t t = r > 138 ? 138 : r;
-                                    rle[o++] = (uint16_t)(18 | ((t - 11) << 8));
-                                    ++n18;
-                                    r -= t;
-                                }
-                                if (r >= 3) {
-                                    rle[o++] = (uint16_t)(17 | ((r - 3) << 8));
-                                    ++n17;
-                                    r = 0;
-                                }
-                                while (r--) {
-                                    rle[o++] = 0;
-                                    ++n0;
-                                }
-                                if (n18) atomicAdd(&clf[18], n18);
-                                if (n17) atomicAdd(&clf[17], n17);
-                                if (n0) atomicAdd(&clf[0], n0);
-                            } else {
-                                uint32_t nv = 1, n16 = 0;
-                                rle[o++] = (uint16_t)v;
-                                --r;
-                                while (r >= 3) {
-                                    const uint32_t t = r > 6 ? 6 : r;
-                                    rle[o++] = (uint16_t)(16 | ((t - 3) << 8));
-                                    ++n16;
-                                    r -= t;
-                                }
-                                while (r--) {
-                                    rle[o++] = (uint16_t)v;
-                                    ++nv;
-                                }
-                                atomicAdd(&clf[v], nv);
-                                if (n16) atomicAdd(&clf[16], n16);
-                            }
-                        }
-                    }
-                    asm volatile("" ::: "memory");
-                    // ---- code-length code (19 symbols, 7 bits) ----
-                    {
-                        uint32_t f = lane < 19 ? clf[lane] : 0u;
-                        const unsigned long long nz = __ballot(f != 0);
-                        if (__builtin_popcountll(nz) < 2 && ulane == ((nz & 1ull) ? 1u : 0u)) f = 1;
-                        uint32_t key = f ? ((f << 9) | ulane) : INF;
-                        key = wave_sort64(key);
-                        const uint32_t mC = (uint32_t)__builtin_popcountll(__ballot(key != INF));
-                        if (lane < 32) TD.sorted[lane] = key;
-                        asm volatile("" ::: "memory");
-                        wave_huffman<1>(TD, mC, 19, 7, cltab);
-                    }
-                    asm volatile("" ::: "memory");
-                    // ---- header bits: every field is OR-merged into the staging words ----
-                    const uint32_t hb = bitpos - base_word * 32;  // bit offset of the header in stage[]
-                    auto put_bits = [&](uint32_t rel, uint32_t v, uint32_t nb) {
-                        // nb <= 17: at most two words
-                        const uint32_t w = rel >> 5, sh = rel & 31;
-                        const uint64_t x = (uint64_t)v << sh;
-                        atomicOr(&stage[w], (uint32_t)x);
-                        if (sh + nb > 32) atomicOr(&stage[w + 1], (uint32_t)(x >> 32));
-                    };
-                    uint32_t hclen;
-                    {
-                        // HCLEN order of the code-length symbols (RFC 1951 3.2.7), order[lane]:
-                        // 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15
-                        const uint64_t oa = 0x0609070800121110ull;  // order[0..7], one byte each
-                        const uint64_t ob = 0x020d030c040b050aull;  // order[8..15]
-                        const uint32_t oc = 0x000f010eu;            // order[16..18]
-                        uint32_t ord = 0;
-                        if (lane < 8)
-                            ord = (uint32_t)(oa >> (8 * ulane)) & 0xffu;
-                        else if (lane < 16)
-                            ord = (uint32_t)(ob >> (8 * (ulane - 8))) & 0xffu;
-                        else if (lane < 19)
-                            ord = (oc >> (8 * (ulane - 16))) & 0xffu;
-                        const uint32_t cll = lane < 19 ? cltab[ord] >> 16 : 0u;
-                        const unsigned long long mu = __ballot(cll != 0);
-                        hclen = 64 - (uint32_t)__builtin_clzll(mu | 1ull);
-                        if (hclen < 4) hclen = 4;
-                        if (lane == 0)
-                            put_bits(hb, bfinal | (2u << 1) | ((hlit - 257) << 3) | ((hdist - 1) << 8) | ((hclen - 4) << 13), 17);
-                        if (ulane < hclen) put_bits(hb + 17 + 3 * ulane, cll, 3);
-                    }
-                    uint32_t pos = hb + 17 + 3 * hclen;
-#pragma unroll
-                    for (int c = 0; c < 5; ++c) {
-                        const uint32_t t = (uint32_t)c * 64 + ulane;
-                        uint32_t v = 0, nb = 0;
-                        if (t < nr) {
-                            const uint32_t it = rle[t], sym = it & 0xffu, ex = it >> 8;
-                            const uint32_t e = cltab[sym];
-                            v = e & 0xffffu;
-                            nb = e >> 16;
-                            v |= ex << nb;
-                            nb += sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u;
-                        }
-                        uint32_t inc = nb;
-#pragma unroll
-                        for (int d = 1; d < 64; d <<= 1) {
-                            const uint32_t y = __shfl_up(inc, d, 64);
-                            if (lane >= d) inc += y;
-                        }
-                        if (nb) put_bits(pos + inc - nb, v, nb);
-                        pos += rl(inc, 63);
-                    }
-                    if (lane == 0) misc[M_TMP] = pos;
-                    PH_END(4);
-                }
-            } else {
-                // fixed Huffman codes (RFC 1951 3.2.6; FixedHuffmanTable rawdeflate.js:48-68)
-                if (tid < 288) {
-                    uint32_t c, l;
-                    if (tid <= 143) {
-                        c = 0x30 + tid;
-                        l = 8;
-                    } else if (tid <= 255) {
-                        c = 0x190 + tid - 144;
-                        l = 9;
-                    } else if (tid <= 279) {
-                        c = tid - 256;
-                        l = 7;
-                    } else {
-                        c = 0xc0 + tid - 280;
-                        l = 8;
-                    }
-                    lltab[tid] = (__brev(c) >> (32 - l)) | (l << 16);
-                }
-                if (tid < 32) dtab[tid] = (__brev((uint32_t)tid) >> 27) | (5u << 16);
-                if (tid == 0) {
-                    bw.put(bfinal, 1);
-                    bw.put(1, 2);
-                    misc[M_TMP] = bw.rel;
-                }
+            if (tid < 320) {
+                P.hist[(size_t)gb * 320 + tid] = tid == 256 ? 1u : fl[tid];  // fl[288] + fd[32] are adjacent
+                fl[tid] = 0;
             }
             __syncthreads();
-            bitpos = base_word * 32 + misc[M_TMP];
-            const uint32_t ntok = misc[M_NTOK];
-            __syncthreads();
-            PH_END(5);
-            // ---- emit tokens: two per thread and pass ----
-            // bits of a pass are OR-merged into the staging words at their prefix-sum
-            // offsets; full words leave with coalesced stores and are cleared by the
-            // thread that stored them, the partial last word moves to the front.
-            for (int i = (S_HUF - S_STAGE) / 4 + tid; i < STAGE_WORDS; i += WG) stage[i] = 0;  // held the tree scratch
-            auto tok_bits = [&](uint32_t tk, uint64_t &bits, uint32_t &nb) {
-                if (!(tk & 0x80000000u)) {
-                    const uint32_t e = lltab[tk];
-                    bits = e & 0xffff;
-                    nb = e >> 16;
-                } else {
-                    uint32_t sym, eb, ev;
-                    len_sym((tk >> 16) & 0xff, sym, eb, ev);
-                    uint32_t e = lltab[sym];
-                    bits = e & 0xffff;
-                    nb = e >> 16;
-                    bits |= (uint64_t)ev << nb;
-                    nb += eb;
-                    dist_sym(tk & 0xffff, sym, eb, ev);
-                    e = dtab[sym];
-                    bits |= (uint64_t)(e & 0xffff) << nb;
-                    nb += e >> 16;
-                    bits |= (uint64_t)ev << nb;
-                    nb += eb;
-                }
-            };
-            auto stage_or = [&](uint32_t rel, uint64_t bits, uint32_t nb) {
-                if (!nb) return;
-                const uint32_t w = rel >> 5, sh = rel & 31;
-                const uint64_t lo = bits << sh;
-                atomicOr(&stage[w], (uint32_t)lo);
-                if ((uint32_t)(lo >> 32)) atomicOr(&stage[w + 1], (uint32_t)(lo >> 32));
-                if (sh && (nb + sh > 64)) atomicOr(&stage[w + 2], (uint32_t)(bits >> (64 - sh)));
-            };
-            for (uint32_t t0 = 0; t0 < ntok; t0 += 2 * WG) {
-                uint64_t b0 = 0, b1 = 0;
-                uint32_t n0 = 0, n1 = 0;
-                const uint32_t ti = t0 + 2 * (uint32_t)tid;
-                if (ti < ntok) {
-                    const uint2 tk = *(const uint2 *)(tokbuf + ti);  // ti is even; the buffer has slack past ntok
-                    tok_bits(tk.x, b0, n0);
-                    if (ti + 1 < ntok) tok_bits(tk.y, b1, n1);
-                }
-                uint32_t total;
-                const uint32_t off = block_scan_excl(n0 + n1, &total, misc + M_SCAN);
-                const uint32_t rel = bitpos + off - base_word * 32;
-                stage_or(rel, b0, n0);
-                stage_or(rel + n0, b1, n1);
-                __syncthreads();
-                bitpos += total;
-                const uint32_t full = (bitpos >> 5) - base_word;
-                if (base_word + full <= cap_words) {
-                    for (uint32_t i = tid; i < full; i += WG) {
-                        out32[base_word + i] = stage[i];
-                        stage[i] = 0;
-                    }
-                } else {
-                    for (uint32_t i = tid; i < full; i += WG) stage[i] = 0;
-                    if (tid == 0) misc[M_OVF] = 1;
-                }
-                if (tid == 0 && full) {
-                    stage[0] = stage[full];
-                    stage[full] = 0;
-                }
-                base_word += full;
-                // the two barriers of the next pass's prefix sum separate this from its ORs
-            }
-            __syncthreads();
-            PH_END(6);
-            carry_word = stage[0];
-            __syncthreads();
-            // reset block state
-            for (int i = tid; i < 320; i += WG) fl[i] = 0;
-            if (tid == 0) misc[M_NTOK] = 0;
-            __syncthreads();
-                };
-
-        if (n == 0) close_block(true);
+        };
+        if (n == 0) flush_block(0);
         for (uint32_t blk_first = 0; blk_first < nitems; blk_first += BLK_ITEMS) {
             const uint32_t blk_end = blk_first + BLK_ITEMS < nitems ? blk_first + BLK_ITEMS : nitems;
             // ---- item loop: every wave takes the next 64 positions, no workgroup barrier ----
             // The parse of an item is deferred until the wave has searched its next item, so
             // that the in-order parse hand-off rarely has to wait for a slower earlier item.
-            // ---- parse bookkeeping shared by the waves (in the phase scratch) ----
+            // ---- parse bookkeeping shared by the waves ----
             // Per in-flight item (slot = item mod NSLOT): for every local index the exit
             // index and the number of tokens when the parse enters the item there, the
             // "searched" stamp, and -- once the parse frontier has passed the item -- its
@@ -959,8 +589,6 @@ zgpu_deflate_kernel(Params P) {
             uint32_t *slot_done = (uint32_t *)(scr + S_DONE);
             uint32_t *slot_entry = (uint32_t *)(scr + S_ENT);
             uint32_t *slot_tokb = (uint32_t *)(scr + S_TOKB);
-            if (tid < (int)NSLOT) slot_done[tid] = 0;  // the scratch held other data during block close
-            __syncthreads();
             auto try_advance = [&]() {
                 if (lane == 0) {
                     for (;;) {
@@ -1251,16 +879,424 @@ zgpu_deflate_kernel(Params P) {
             __syncthreads();
             PH_END(1);
             if (tid == 0) misc[M_ITEM] = blk_end;  // the counter overshoots by one per wave
-            close_block(blk_end == nitems);
+            flush_block(blk_first / BLK_ITEMS);
+            tokbuf += ZGPU_BLOCK_TOK;
         }
 
-        // ---- finish the unit ----
         PH_FLUSH();
 #ifdef ZGPU_PROFILE
         for (int i_ = 0; i_ < 16; ++i_) ph_acc[i_] = 0;
 #endif
+    }
+}
+
+namespace {
+
+// ---- emit kernel ------------------------------------------------------------
+// One 256-thread workgroup per unit (persistent over the unit queue) turns the
+// token streams and histograms the search kernel left in global memory into
+// DEFLATE blocks: Huffman codes (dynamic) or the fixed tables, the block header,
+// and the token bits -- prefix sum of bit lengths, OR-merge into LDS staging
+// words, coalesced dword stores.  Blocks of a unit follow each other at bit
+// granularity, so a unit's blocks are emitted in order by one workgroup; many
+// workgroups share a CU and hide each other's serial stretches.
+struct EParams {
+    const uint64_t *in_off;    // n_units+1 (unit sizes)
+    const uint64_t *slot_off;  // n_units+1, 16-byte aligned output slots in out_tmp
+    uint8_t *out_tmp;
+    uint32_t *out_size;        // n_units
+    uint32_t *status;          // n_units
+    const uint32_t *tok;       // token buffer of this round
+    const uint64_t *tok_off;   // n_units: first token of the unit within tok
+    const uint32_t *blk_first; // n_units: index of the unit's first block
+    const uint32_t *hist;      // blocks x 320 symbol counts (lit/len 288, dist 32)
+    const uint32_t *ntok;      // blocks: tokens incl. end-of-block
+    uint32_t *counter;         // unit queue head (relative to unit_first)
+    uint32_t unit_first, unit_end, n_units;
+    int ctype;
+    uint32_t flags;
+};
+
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(EWG, 8)
+zgpu_emit_kernel(EParams P) {
+    __shared__ __align__(16) uint8_t lds[E_TOTAL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *fl = (uint32_t *)(lds + E_FL), *fd = fl + 288, *misc = (uint32_t *)(lds + E_MISC);
+    uint32_t *lltab = (uint32_t *)(lds + E_LLTAB), *dtab = (uint32_t *)(lds + E_DTAB);
+    uint32_t *stage = (uint32_t *)(lds + E_STAGE);
+    for (;;) {
+        if (tid == 0) misc[M_UNIT] = P.unit_first + atomicAdd(P.counter, 1u);
+        __syncthreads();
+        const uint32_t u = misc[M_UNIT];
+        __syncthreads();
+        if (u >= P.unit_end) break;
+        const uint32_t n = (uint32_t)(P.in_off[u + 1] - P.in_off[u]);
+        uint32_t *out32 = (uint32_t *)(P.out_tmp + P.slot_off[u]);
+        const uint32_t cap_words = (uint32_t)((P.slot_off[u + 1] - P.slot_off[u]) >> 2);
+        const bool final_unit =
+            (P.flags & 1u) || ((P.flags & 4u) && u == P.n_units - 1) || !(P.flags & 2u);
+        const uint32_t nblk = n ? (n + ZGPU_BLOCK_BYTES - 1) / ZGPU_BLOCK_BYTES : 1u;
+        uint32_t bitpos = 0;     // bits emitted so far in this unit (uniform)
+        uint32_t base_word = 0;  // output word index of stage[0] (uniform)
+        if (tid == 0) misc[M_OVF] = 0;
+        for (int i = tid; i < STAGE_WORDS; i += EWG) stage[i] = 0;
+        for (uint32_t blk = 0; blk < nblk; ++blk) {
+            const uint32_t gb = P.blk_first[u] + blk;
+            const uint32_t *tokbuf = P.tok + P.tok_off[u] + (uint64_t)blk * ZGPU_BLOCK_TOK;
+            const uint32_t ntok = P.ntok[gb];
+            const uint32_t bfinal = (blk + 1 == nblk && final_unit) ? 1u : 0u;
+            for (int i = tid; i < 320; i += EWG) fl[i] = P.hist[(size_t)gb * 320 + i];
+            __syncthreads();
+            // stage[] holds the unit's partial last word at [0] and is zero elsewhere
+            BitW bw{stage, bitpos - base_word * 32};
+            if (P.ctype == 2) {
+                const HufS TL = huf_scratch(lds + E_HUF + H_TL, 288), TD = huf_scratch(lds + E_HUF + H_TD, 32);
+                const uint32_t INF = 0xffffffffu;
+                // every code set gets at least two symbols, so it is complete: a block that
+                // holds only the end-of-block symbol gains literal 0, and the distance
+                // alphabet is topped up to two used symbols
+                if (tid == 0 && ntok < 2) fl[0] = 1;
+                if (wave == 1) {
+                    const unsigned long long nz = __ballot(lane < 30 && fd[lane] != 0);
+                    const int c = __builtin_popcountll(nz);
+                    if (c < 2 && lane == 0) {
+                        if (c == 0) fd[0] = 1;
+                        fd[(c == 0 || (nz & 1ull)) ? 1 : 0] = 1;
+                    }
+                }
+                __syncthreads();
+                // ---- sort keys (weight << 9 | symbol, unused = INF) ----
+                for (int i = tid; i < 288; i += EWG)
+                    TL.niw[i] = (i < 286 && fl[i]) ? ((fl[i] << 9) | (uint32_t)i) : INF;
+                if (tid < 32) TD.niw[tid] = (tid < 30 && fd[tid]) ? ((fd[tid] << 9) | (uint32_t)tid) : INF;
+                __syncthreads();
+                // ---- rank sort: a key's rank is the number of smaller keys ----
+                uint32_t rk0 = 0, rk1 = 0, key0, key1 = INF;
+                {
+                    key0 = TL.niw[tid];
+                    const bool second = tid < 32 || (tid >= 64 && tid < 96);  // lit/len 256.., dist keys
+                    const uint32_t *k1src = tid < 32 ? TL.niw + 256 + tid : TD.niw + (tid - 64);
+                    if (second) key1 = *k1src;
+                    const uint4 *kp = (const uint4 *)TL.niw;
+#pragma unroll 4
+                    for (int j = 0; j < 72; ++j) {
+                        const uint4 q = kp[j];
+                        rk0 += (q.x < key0) + (q.y < key0) + (q.z < key0) + (q.w < key0);
+                    }
+                    if (tid < 32) {
+                        for (int j = 0; j < 72; ++j) {
+                            const uint4 q = kp[j];
+                            rk1 += (q.x < key1) + (q.y < key1) + (q.z < key1) + (q.w < key1);
+                        }
+                    } else if (second) {
+                        for (int j = 0; j < 32; ++j) rk1 += TD.niw[j] < key1;
+                    }
+                }
+                // a padding key's rank is the number of used symbols
+                if (tid == 31) misc[M_NTOK] = rk1;  // lit/len key 287
+                if (tid == 95) misc[M_TMP] = rk1;   // dist key 31
+                if (key0 != INF) TL.sorted[rk0] = key0;
+                if (key1 != INF) (tid < 32 ? TL.sorted : TD.sorted)[rk1] = key1;
+                __syncthreads();
+                const uint32_t mL = misc[M_NTOK], mD = misc[M_TMP];
+                // ---- the two trees, one wave each ----
+                if (wave == 0) wave_huffman<5>(TL, mL, 286, 15, lltab);
+                if (wave == 1) wave_huffman<1>(TD, mD, 30, 15, dtab);
+                __syncthreads();
+                // ---- header (wave 0): HLIT/HDIST, run-length items, code-length code, bits ----
+                if (wave == 0) {
+                    uint16_t *rle = (uint16_t *)(lds + E_HUF + H_RLE);
+                    uint32_t *clf = (uint32_t *)(lds + E_HUF + H_CLF);
+                    uint32_t *cltab = (uint32_t *)(lds + E_HUF + H_CLTAB);
+                    const uint32_t ulane = (uint32_t)lane;
+                    if (lane < 32) clf[lane] = 0;
+                    // HLIT / HDIST: trailing unused symbols are not sent (at least 257 / 1)
+                    uint32_t hlit, hdist;
+                    {
+                        const unsigned long long mh = __ballot(256 + lane < 286 && (lltab[256 + lane] >> 16) != 0);
+                        hlit = 256 + 64 - (uint32_t)__builtin_clzll(mh | 1ull);  // symbol 256 is always used
+                        if (hlit < 257) hlit = 257;
+                        const unsigned long long md = __ballot(lane < 30 && (dtab[lane & 31] >> 16) != 0);
+                        hdist = 64 - (uint32_t)__builtin_clzll(md | 1ull);
+                    }
+                    const uint32_t tot = hlit + hdist;
+                    // code lengths of the concatenated alphabets, 64 per chunk; run starts
+                    uint32_t Lv[5];
+                    unsigned long long St[5];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        const uint32_t i = (uint32_t)c * 64 + ulane;
+                        Lv[c] = i < hlit ? lltab[i] >> 16 : (i < tot ? dtab[(i - hlit) & 31] >> 16 : 0xffu);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        const uint32_t i = (uint32_t)c * 64 + ulane;
+                        const uint32_t pl = c ? rl(Lv[c ? c - 1 : 0], 63) : 0xffffu;  // last of the previous chunk
+                        uint32_t pv = __shfl_up(Lv[c], 1, 64);
+                        if (lane == 0) pv = pl;
+                        St[c] = __ballot(i <= tot && (i == tot || Lv[c] != pv));  // index tot closes the last run
+                    }
+                    // items per run (greedy: 18 for 11..138 zeros, 17 for 3..10, 16 for 3..6 repeats)
+                    uint32_t run[5], cnt[5], off[5];
+                    uint32_t nr = 0;
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        const uint32_t i = (uint32_t)c * 64 + ulane;
+                        const bool start = i < tot && ((St[c] >> ulane) & 1ull);
+                        uint32_t nxt = tot;
+                        {
+                            const unsigned long long above = lane == 63 ? 0ull : (St[c] >> (ulane + 1)) << (ulane + 1);
+                            bool found = false;
+                            if (above) {
+                                nxt = (uint32_t)c * 64 + (uint32_t)__builtin_ctzll(above);
+                                found = true;
+                            }
+#pragma unroll
+                            for (int c2 = c + 1; c2 < 5; ++c2)
+                                if (!found && St[c2]) {
+                                    nxt = (uint32_t)c2 * 64 + (uint32_t)__builtin_ctzll(St[c2]);
+                                    found = true;
+                                }
+                        }
+                        uint32_t r = start ? nxt - i : 0u, n = 0;
+                        if (start) {
+                            if (Lv[c] == 0) {
+                                const uint32_t q = r / 138u, rem = r % 138u;
+                                n = q + (rem >= 3 ? 1u : rem);
+                            } else {
+                                const uint32_t q = (r - 1) / 6u, rem = (r - 1) % 6u;
+                                n = 1 + q + (rem >= 3 ? 1u : rem);
+                            }
+                        }
+                        run[c] = r;
+                        cnt[c] = n;
+                        uint32_t inc = n;
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) {
+                            const uint32_t y = __shfl_up(inc, d, 64);
+                            if (lane >= d) inc += y;
+                        }
+                        off[c] = nr + inc - n;
+                        nr += rl(inc, 63);
+                    }
+                    // write the items, count the code-length symbols
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        if (cnt[c]) {
+                            uint32_t r = run[c], o = off[c];
+                            const uint32_t v = Lv[c];
+                            if (v == 0) {
+                                uint32_t n18 = 0, n17 = 0, n0 = 0;
+                                while (r >= 11) {
+                                    const uint32_t t = r > 138 ? 138 : r;
+                                    rle[o++] = (uint16_t)(18 | ((t - 11) << 8));
+                                    ++n18;
+                                    r -= t;
+                                }
+                                if (r >= 3) {
+                                    rle[o++] = (uint16_t)(17 | ((r - 3) << 8));
+                                    ++n17;
+                                    r = 0;
+                                }
+                                while (r--) {
+                                    rle[o++] = 0;
+                                    ++n0;
+                                }
+                                if (n18) atomicAdd(&clf[18], n18);
+                                if (n17) atomicAdd(&clf[17], n17);
+                                if (n0) atomicAdd(&clf[0], n0);
+                            } else {
+                                uint32_t nv = 1, n16 = 0;
+                                rle[o++] = (uint16_t)v;
+                                --r;
+                                while (r >= 3) {
+                                    const uint32_t t = r > 6 ? 6 : r;
+                                    rle[o++] = (uint16_t)(16 | ((t - 3) << 8));
+                                    ++n16;
+                                    r -= t;
+                                }
+                                while (r--) {
+                                    rle[o++] = (uint16_t)v;
+                                    ++nv;
+                                }
+                                atomicAdd(&clf[v], nv);
+                                if (n16) atomicAdd(&clf[16], n16);
+                            }
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+                    // ---- code-length code (19 symbols, 7 bits) ----
+                    {
+                        uint32_t f = lane < 19 ? clf[lane] : 0u;
+                        const unsigned long long nz = __ballot(f != 0);
+                        if (__builtin_popcountll(nz) < 2 && ulane == ((nz & 1ull) ? 1u : 0u)) f = 1;
+                        uint32_t key = f ? ((f << 9) | ulane) : INF;
+                        key = wave_sort64(key);
+                        const uint32_t mC = (uint32_t)__builtin_popcountll(__ballot(key != INF));
+                        if (lane < 32) TD.sorted[lane] = key;
+                        asm volatile("" ::: "memory");
+                        wave_huffman<1>(TD, mC, 19, 7, cltab);
+                    }
+                    asm volatile("" ::: "memory");
+                    // ---- header bits: every field is OR-merged into the staging words ----
+                    const uint32_t hb = bitpos - base_word * 32;  // bit offset of the header in stage[]
+                    auto put_bits = [&](uint32_t rel, uint32_t v, uint32_t nb) {
+                        // nb <= 17: at most two words
+                        const uint32_t w = rel >> 5, sh = rel & 31;
+                        const uint64_t x = (uint64_t)v << sh;
+                        atomicOr(&stage[w], (uint32_t)x);
+                        if (sh + nb > 32) atomicOr(&stage[w + 1], (uint32_t)(x >> 32));
+                    };
+                    uint32_t hclen;
+                    {
+                        // HCLEN order of the code-length symbols (RFC 1951 3.2.7), order[lane]:
+                        // 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15
+                        const uint64_t oa = 0x0609070800121110ull;  // order[0..7], one byte each
+                        const uint64_t ob = 0x020d030c040b050aull;  // order[8..15]
+                        const uint32_t oc = 0x000f010eu;            // order[16..18]
+                        uint32_t ord = 0;
+                        if (lane < 8)
+                            ord = (uint32_t)(oa >> (8 * ulane)) & 0xffu;
+                        else if (lane < 16)
+                            ord = (uint32_t)(ob >> (8 * (ulane - 8))) & 0xffu;
+                        else if (lane < 19)
+                            ord = (oc >> (8 * (ulane - 16))) & 0xffu;
+                        const uint32_t cll = lane < 19 ? cltab[ord] >> 16 : 0u;
+                        const unsigned long long mu = __ballot(cll != 0);
+                        hclen = 64 - (uint32_t)__builtin_clzll(mu | 1ull);
+                        if (hclen < 4) hclen = 4;
+                        if (lane == 0)
+                            put_bits(hb, bfinal | (2u << 1) | ((hlit - 257) << 3) | ((hdist - 1) << 8) | ((hclen - 4) << 13), 17);
+                        if (ulane < hclen) put_bits(hb + 17 + 3 * ulane, cll, 3);
+                    }
+                    uint32_t pos = hb + 17 + 3 * hclen;
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        const uint32_t t = (uint32_t)c * 64 + ulane;
+                        uint32_t v = 0, nb = 0;
+                        if (t < nr) {
+                            const uint32_t it = rle[t], sym = it & 0xffu, ex = it >> 8;
+                            const uint32_t e = cltab[sym];
+                            v = e & 0xffffu;
+                            nb = e >> 16;
+                            v |= ex << nb;
+                            nb += sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u;
+                        }
+                        uint32_t inc = nb;
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) {
+                            const uint32_t y = __shfl_up(inc, d, 64);
+                            if (lane >= d) inc += y;
+                        }
+                        if (nb) put_bits(pos + inc - nb, v, nb);
+                        pos += rl(inc, 63);
+                    }
+                    if (lane == 0) misc[M_TMP] = pos;
+                }
+            } else {
+                // fixed Huffman codes (RFC 1951 3.2.6; FixedHuffmanTable rawdeflate.js:48-68)
+                for (int sy = tid; sy < 288; sy += EWG) {
+                    uint32_t c, l;
+                    if (sy <= 143) {
+                        c = 0x30 + sy;
+                        l = 8;
+                    } else if (sy <= 255) {
+                        c = 0x190 + sy - 144;
+                        l = 9;
+                    } else if (sy <= 279) {
+                        c = sy - 256;
+                        l = 7;
+                    } else {
+                        c = 0xc0 + sy - 280;
+                        l = 8;
+                    }
+                    lltab[sy] = (__brev(c) >> (32 - l)) | (l << 16);
+                }
+                if (tid < 32) dtab[tid] = (__brev((uint32_t)tid) >> 27) | (5u << 16);
+                if (tid == 0) {
+                    bw.put(bfinal, 1);
+                    bw.put(1, 2);
+                    misc[M_TMP] = bw.rel;
+                }
+            }
+            __syncthreads();
+            bitpos = base_word * 32 + misc[M_TMP];
+            __syncthreads();
+            // ---- emit tokens: two per thread and pass ----
+            // bits of a pass are OR-merged into the staging words at their prefix-sum
+            // offsets; full words leave with coalesced stores and are cleared by the
+            // thread that stored them, the partial last word moves to the front.
+            auto tok_bits = [&](uint32_t tk, uint64_t &bits, uint32_t &nb) {
+                if (!(tk & 0x80000000u)) {
+                    const uint32_t e = lltab[tk];
+                    bits = e & 0xffff;
+                    nb = e >> 16;
+                } else {
+                    uint32_t sym, eb, ev;
+                    len_sym((tk >> 16) & 0xff, sym, eb, ev);
+                    uint32_t e = lltab[sym];
+                    bits = e & 0xffff;
+                    nb = e >> 16;
+                    bits |= (uint64_t)ev << nb;
+                    nb += eb;
+                    dist_sym(tk & 0xffff, sym, eb, ev);
+                    e = dtab[sym];
+                    bits |= (uint64_t)(e & 0xffff) << nb;
+                    nb += e >> 16;
+                    bits |= (uint64_t)ev << nb;
+                    nb += eb;
+                }
+            };
+            auto stage_or = [&](uint32_t rel, uint64_t bits, uint32_t nb) {
+                if (!nb) return;
+                const uint32_t w = rel >> 5, sh = rel & 31;
+                const uint64_t lo = bits << sh;
+                atomicOr(&stage[w], (uint32_t)lo);
+                if ((uint32_t)(lo >> 32)) atomicOr(&stage[w + 1], (uint32_t)(lo >> 32));
+                if (sh && (nb + sh > 64)) atomicOr(&stage[w + 2], (uint32_t)(bits >> (64 - sh)));
+            };
+            for (uint32_t t0 = 0; t0 < ntok; t0 += ETOK) {
+                uint64_t b0 = 0, b1 = 0;
+                uint32_t n0 = 0, n1 = 0;
+                const uint32_t ti = t0 + 2 * (uint32_t)tid;
+                if (ti < ntok) {
+                    const uint2 tk = *(const uint2 *)(tokbuf + ti);  // ti is even; block regions are even-sized
+                    tok_bits(tk.x, b0, n0);
+                    if (ti + 1 < ntok) tok_bits(tk.y, b1, n1);
+                }
+                uint32_t total;
+                const uint32_t off = block_scan_excl<EWG / 64>(n0 + n1, &total, misc + M_SCAN);
+                const uint32_t rel = bitpos + off - base_word * 32;
+                stage_or(rel, b0, n0);
+                stage_or(rel + n0, b1, n1);
+                __syncthreads();
+                bitpos += total;
+                const uint32_t full = (bitpos >> 5) - base_word;
+                if (base_word + full <= cap_words) {
+                    for (uint32_t i = tid; i < full; i += EWG) {
+                        out32[base_word + i] = stage[i];
+                        stage[i] = 0;
+                    }
+                } else {
+                    for (uint32_t i = tid; i < full; i += EWG) stage[i] = 0;
+                    if (tid == 0) misc[M_OVF] = 1;
+                }
+                if (tid == 0 && full) {
+                    stage[0] = stage[full];
+                    stage[full] = 0;
+                }
+                base_word += full;
+                // the two barriers of the next pass's prefix sum separate this from its ORs
+            }
+            __syncthreads();
+        }
+        // ---- finish the unit: byte-align, or an empty stored block for a chunk that is
+        // followed by more of the same stream ----
         if (tid == 0) {
-            uint32_t bp = bitpos, cw = carry_word, bwd = base_word;
+            uint32_t bp = bitpos, cw = stage[0], bwd = base_word;
+            stage[0] = 0;
             bool ovf = misc[M_OVF] != 0;
             auto put = [&](uint32_t v, uint32_t nb) {
                 // serial writer straight to the output (at most a few words)
@@ -1280,7 +1316,7 @@ zgpu_deflate_kernel(Params P) {
                     }
                 }
             };
-            if (sync_unit) {
+            if (!final_unit) {
                 put(0, 3);  // BFINAL=0, BTYPE=00
                 put(0, (8 - (bp & 7)) & 7);
                 put(0x0000, 16);

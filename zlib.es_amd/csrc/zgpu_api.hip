@@ -127,11 +127,24 @@ struct zgpu_plan {
     uint64_t *d_in_off = nullptr, *d_slot_off = nullptr, *d_out_off = nullptr;
     uint32_t *d_out_size = nullptr, *d_status = nullptr, *d_crc = nullptr, *d_adler = nullptr;
     uint32_t *d_tok = nullptr, *d_counter = nullptr;
+    uint64_t *d_tok_off = nullptr;   // per unit: first token within its round's buffer
+    uint32_t *d_blk_first = nullptr; // per unit: index of its first block
+    uint32_t *d_hist = nullptr, *d_ntok = nullptr;  // per block
     uint8_t *d_out_tmp = nullptr;
-    int grid = 0;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    struct Round { uint32_t first, end; };
+    std::vector<Round> rounds;       // units whose tokens share the token buffer at one time
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ran = false;
 };
+
+namespace {
+uint64_t unit_blocks(uint64_t n) { return n ? (n + ZGPU_BLOCK_BYTES - 1) / ZGPU_BLOCK_BYTES : 1; }
+// tokens reserved for a unit: full blocks at their fixed stride, the last one exact (even)
+uint64_t unit_tok_cap(uint64_t n) {
+    const uint64_t nb = unit_blocks(n), last = n - (nb - 1) * ZGPU_BLOCK_BYTES;
+    return (nb - 1) * ZGPU_BLOCK_TOK + ((last + 1 + 1) & ~1ull) + 2;
+}
+}  // namespace
 
 extern "C" {
 
@@ -241,9 +254,39 @@ int zgpu_plan_create(zgpu_plan **out, const uint64_t *in_off, uint32_t n_units, 
     slot[n_units] = acc;
     p->tmp_bytes = acc;
     p->out_bound = acc;
-    p->grid = (int)((uint64_t)ds->cus * ZGPU_DEFLATE_WG_PER_CU < n_units
-                        ? (uint64_t)ds->cus * ZGPU_DEFLATE_WG_PER_CU
-                        : n_units);
+    // Token scratch: 4 bytes per input byte in the worst case.  Units are cut into rounds
+    // whose tokens fit a buffer of at most a third of the free device memory (ZGPU_TOK_BYTES
+    // overrides; never less than one maximum-size unit needs).
+    std::vector<uint64_t> tok_off(n_units);
+    std::vector<uint32_t> blk_first(n_units);
+    uint64_t tok_buf_tokens = 0, n_blocks = 0;
+    if (ctype != ZGPU_NONE) {
+        size_t free_b = 0, total_b = 0;
+        uint64_t cap_bytes = 8ull << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap_bytes = free_b / 3;
+        if (const char *e = getenv("ZGPU_TOK_BYTES")) cap_bytes = strtoull(e, nullptr, 10);
+        const uint64_t cap_tokens = cap_bytes / 4;
+        uint64_t used = 0;
+        uint32_t first = 0;
+        for (uint32_t i = 0; i < n_units; ++i) {
+            const uint64_t n = in_off[i + 1] - in_off[i], need = unit_tok_cap(n);
+            if (used && used + need > cap_tokens) {
+                p->rounds.push_back({first, i});
+                first = i;
+                used = 0;
+            }
+            tok_off[i] = used;
+            used += need;
+            if (used > tok_buf_tokens) tok_buf_tokens = used;
+            if (n_blocks + unit_blocks(n) > 0xffffffffull) {
+                delete p;
+                return ZGPU_E_TOOBIG;
+            }
+            blk_first[i] = (uint32_t)n_blocks;
+            n_blocks += unit_blocks(n);
+        }
+        p->rounds.push_back({first, n_units});
+    }
 #define PCHK(expr)                 \
     do {                           \
         hipError_t e_ = (expr);    \
@@ -261,14 +304,22 @@ int zgpu_plan_create(zgpu_plan **out, const uint64_t *in_off, uint32_t n_units, 
     PCHK(hipMalloc(&p->d_status, (size_t)n_units * 4));
     PCHK(hipMalloc(&p->d_crc, (size_t)n_units * 4));
     PCHK(hipMalloc(&p->d_adler, (size_t)n_units * 4));
-    PCHK(hipMalloc(&p->d_counter, 256));
+    PCHK(hipMalloc(&p->d_counter, (p->rounds.size() * 2 + 2) * 4));
     PCHK(hipMalloc(&p->d_out_tmp, p->tmp_bytes + 64));
-    if (ctype != ZGPU_NONE) PCHK(hipMalloc(&p->d_tok, (size_t)p->grid * ZGPU_TOK_CAP * 4));
+    if (ctype != ZGPU_NONE) {
+        PCHK(hipMalloc(&p->d_tok, (size_t)tok_buf_tokens * 4 + 64));
+        PCHK(hipMalloc(&p->d_tok_off, (size_t)n_units * 8));
+        PCHK(hipMalloc(&p->d_blk_first, (size_t)n_units * 4));
+        PCHK(hipMalloc(&p->d_hist, (size_t)n_blocks * 320 * 4));
+        PCHK(hipMalloc(&p->d_ntok, (size_t)n_blocks * 4));
+        PCHK(hipMemcpy(p->d_tok_off, tok_off.data(), (size_t)n_units * 8, hipMemcpyHostToDevice));
+        PCHK(hipMemcpy(p->d_blk_first, blk_first.data(), (size_t)n_units * 4, hipMemcpyHostToDevice));
+    }
     PCHK(hipMemcpy(p->d_in_off, in_off, offb, hipMemcpyHostToDevice));
     PCHK(hipMemcpy(p->d_slot_off, slot.data(), offb, hipMemcpyHostToDevice));
     PCHK(hipMemset(p->d_crc, 0, (size_t)n_units * 4));
     PCHK(hipMemset(p->d_adler, 0, (size_t)n_units * 4));
-    for (int i = 0; i < 4; ++i) PCHK(hipEventCreate(&p->ev[i]));
+    for (int i = 0; i < 5; ++i) PCHK(hipEventCreate(&p->ev[i]));
 #undef PCHK
     *out = p;
     return ZGPU_OK;
@@ -286,7 +337,11 @@ void zgpu_plan_destroy(zgpu_plan *p) {
     (void)hipFree(p->d_counter);
     (void)hipFree(p->d_out_tmp);
     (void)hipFree(p->d_tok);
-    for (int i = 0; i < 4; ++i)
+    (void)hipFree(p->d_tok_off);
+    (void)hipFree(p->d_blk_first);
+    (void)hipFree(p->d_hist);
+    (void)hipFree(p->d_ntok);
+    for (int i = 0; i < 5; ++i)
         if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
     delete p;
 }
@@ -297,31 +352,55 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
     if (!p || !d_out || (!d_in && p->in_total)) return ZGPU_E_ARG;
     hipStream_t st = (hipStream_t)stream_;
     HIPCHK(hipEventRecord(p->ev[0], st));
-    HIPCHK(hipMemsetAsync(p->d_counter, 0, 4, st));
+    HIPCHK(hipMemsetAsync(p->d_counter, 0, (p->rounds.size() * 2 + 2) * 4, st));
     HIPCHK(hipEventRecord(p->ev[1], st));
     if (p->ctype == ZGPU_NONE) {
         int grid = p->n_units < (uint32_t)p->ds->cus * 8 ? (int)p->n_units : p->ds->cus * 8;
         hipLaunchKernelGGL(zgpu_stored_kernel, dim3(grid), dim3(256), 0, st, (const uint8_t *)d_in,
                            p->d_in_off, p->d_slot_off, p->d_out_tmp, p->d_out_size, p->d_status,
                            p->n_units, p->flags);
+        HIPCHK(hipEventRecord(p->ev[4], st));
     } else {
-        Params P;
-        P.in = (const uint8_t *)d_in;
-        P.in_off = p->d_in_off;
-        P.slot_off = p->d_slot_off;
-        P.out_tmp = p->d_out_tmp;
-        P.out_size = p->d_out_size;
-        P.status = p->d_status;
-        P.tok = p->d_tok;
-        P.counter = p->d_counter;
-        P.n_units = p->n_units;
-        P.ctype = p->ctype;
-        P.lazy = p->lazy > g_min_lazy ? p->lazy : g_min_lazy;
-        P.max_chain = g_max_chain;
-        P.nice = g_nice;
-        P.flags = p->flags;
-        P.prof = g_prof;
-        hipLaunchKernelGGL(zgpu_deflate_kernel, dim3(p->grid), dim3(1024), 0, st, P);
+        for (size_t r = 0; r < p->rounds.size(); ++r) {
+            const uint32_t first = p->rounds[r].first, end = p->rounds[r].end, cnt = end - first;
+            Params P;
+            P.in = (const uint8_t *)d_in;
+            P.in_off = p->d_in_off;
+            P.tok = p->d_tok;
+            P.tok_off = p->d_tok_off;
+            P.blk_first = p->d_blk_first;
+            P.hist = p->d_hist;
+            P.ntok = p->d_ntok;
+            P.counter = p->d_counter + 2 * r;
+            P.unit_first = first;
+            P.unit_end = end;
+            P.lazy = p->lazy > g_min_lazy ? p->lazy : g_min_lazy;
+            P.max_chain = g_max_chain;
+            P.nice = g_nice;
+            P.prof = g_prof;
+            const int sgrid = (int)(cnt < (uint32_t)p->ds->cus ? cnt : (uint32_t)p->ds->cus);
+            hipLaunchKernelGGL(zgpu_deflate_kernel, dim3(sgrid), dim3(1024), 0, st, P);
+            if (r == 0) HIPCHK(hipEventRecord(p->ev[4], st));
+            EParams E;
+            E.in_off = p->d_in_off;
+            E.slot_off = p->d_slot_off;
+            E.out_tmp = p->d_out_tmp;
+            E.out_size = p->d_out_size;
+            E.status = p->d_status;
+            E.tok = p->d_tok;
+            E.tok_off = p->d_tok_off;
+            E.blk_first = p->d_blk_first;
+            E.hist = p->d_hist;
+            E.ntok = p->d_ntok;
+            E.counter = p->d_counter + 2 * r + 1;
+            E.unit_first = first;
+            E.unit_end = end;
+            E.n_units = p->n_units;
+            E.ctype = p->ctype;
+            E.flags = p->flags;
+            const uint32_t emax = (uint32_t)p->ds->cus * ZGPU_EMIT_WG_PER_CU;
+            hipLaunchKernelGGL(zgpu_emit_kernel, dim3(cnt < emax ? cnt : emax), dim3(256), 0, st, E);
+        }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(p->ev[2], st));
@@ -372,6 +451,17 @@ int zgpu_plan_kernel_ms(zgpu_plan *p, float *deflate_ms, float *total_ms) {
     HIPCHK(hipEventSynchronize(p->ev[3]));
     if (deflate_ms) HIPCHK(hipEventElapsedTime(deflate_ms, p->ev[1], p->ev[2]));
     if (total_ms) HIPCHK(hipEventElapsedTime(total_ms, p->ev[0], p->ev[3]));
+    return ZGPU_OK;
+}
+
+int zgpu_plan_phase_ms(zgpu_plan *p, float *search_ms, float *emit_ms) {
+    if (!p || !p->ran) return ZGPU_E_ARG;
+    HIPCHK(hipEventSynchronize(p->ev[3]));
+    if (search_ms) HIPCHK(hipEventElapsedTime(search_ms, p->ev[1], p->ev[4]));
+    if (emit_ms) {
+        *emit_ms = 0.f;
+        if (p->rounds.size() == 1) HIPCHK(hipEventElapsedTime(emit_ms, p->ev[4], p->ev[2]));
+    }
     return ZGPU_OK;
 }
 

@@ -2,11 +2,15 @@
 #pragma once
 #include <stdint.h>
 
-// tokens one workgroup can hold for one DEFLATE block (64 KiB of input can
-// yield at most 65536 tokens, plus end-of-block and the final literal)
-#define ZGPU_TOK_CAP (65536u + 64u)
+// one DEFLATE block per this many input bytes; a block yields at most that many
+// tokens plus end-of-block, and block b of a unit starts ZGPU_BLOCK_TOK * b
+// tokens into the unit's token region (even, so two tokens load as one 8 bytes)
+#define ZGPU_BLOCK_BYTES 65536u
+#define ZGPU_BLOCK_TOK (ZGPU_BLOCK_BYTES + 2u)
 // workgroups of the DEFLATE kernel that fit one CU (LDS-bound)
 #define ZGPU_DEFLATE_WG_PER_CU 1
+// workgroups of the emit kernel queued per CU (small LDS footprint, latency bound)
+#define ZGPU_EMIT_WG_PER_CU 8
 
 // checksum kernel geometry: every workgroup folds ZGPU_CK_SEG bytes
 #define ZGPU_CK_THREADS 256
