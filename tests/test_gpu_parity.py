@@ -153,6 +153,22 @@ def test_sync_align_concatenates(z):
         assert o[-4:] == b"\x00\x00\xff\xff"
 
 
+def test_token_scratch_rounds(z, monkeypatch):
+    # a small token-scratch cap cuts the batch into several rounds of units; the result
+    # must not depend on where the cuts fall (one unit alone exceeds the cap, too)
+    datas = [zo.gen({"gen": "text", "n": 65536, "seed": s}) for s in range(10)]
+    datas.insert(3, zo.gen({"gen": "rndseq", "n": 400_000, "seed": 5}))
+    datas.append(np.zeros(0, dtype=np.uint8))
+    datas.append(zo.gen({"gen": "rnd", "n": 70_000, "seed": 8}))
+    ref, _, _ = z.deflate_batch(datas, 2, 0)
+    monkeypatch.setenv("ZGPU_TOK_BYTES", str(1 << 20))
+    got, crc, _ = z.deflate_batch(datas, 2, 0, want_crc=True)
+    assert [bytes(g) for g in got] == [bytes(r) for r in ref]
+    for d, o, c in zip(datas, got, crc):
+        assert zo.inflate_raw(bytes(o), d.size) == d.tobytes()
+        assert int(c) == zo.crc32(d)
+
+
 def test_invalid_arguments(z):
     with pytest.raises(z.ZgpuError):
         z.deflate_batch([b"abc"], 3)
