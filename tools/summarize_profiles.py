@@ -57,6 +57,25 @@ def main():
                 out.setdefault(sub, {}).setdefault(k, {})[c] = x / max(1, calls[k])
     with open(os.path.join(DST, "%s_pmc.json" % tag), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
+    # HBM-side traffic of the default bench workload, per launch of the DEFLATE path
+    # (search + emit kernels).  FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE
+    # reports half the bytes of wide (16 B per lane) streaming reads, so it is doubled.
+    try:
+        f_kb = sum(out["fetch"][k]["FETCH_SIZE"] for k in ("zgpu_deflate_kernel", "zgpu_emit_kernel"))
+        w_kb = sum(out["write"][k]["WRITE_SIZE"] for k in ("zgpu_deflate_kernel", "zgpu_emit_kernel"))
+        traffic = {
+            "workload": {"units": 65536, "unit_bytes": 65536, "ctype": 2, "lazy": 0},
+            "bytes_per_launch": int((2 * f_kb + w_kb) * 1024),
+            "fetch_size_kb_raw": f_kb, "write_size_kb_raw": w_kb,
+            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), sum of zgpu_deflate_kernel and "
+                    "zgpu_emit_kernel, FETCH_SIZE doubled (gfx950 counts 128-B read requests at 64 B); the token "
+                    "stream between the two kernels is part of it",
+            "source": "%s_pmc.json" % tag,
+        }
+        with open(os.path.join(DST, "traffic.json"), "w") as f:
+            json.dump(traffic, f, indent=1)
+    except KeyError:
+        pass
     print(json.dumps(out, indent=1, sort_keys=True))
 
 
