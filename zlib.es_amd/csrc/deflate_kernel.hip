@@ -737,8 +737,10 @@ zgpu_deflate_kernel(Params P) {
                 }
                 PH_END(8);
                 // ---- insert: sort (hash, lane) in registers, link chains in item order ----
+                // this position's first 16 bytes: hashed here, compared against candidates below
+                const v4u own = ld16(ring + (p & (RING - 1)));
                 uint32_t key = 0xffffffffu;
-                if (p + 3 <= n) key = (hash3(ld4(ring + (p & (RING - 1)))) << 6) | (uint32_t)lane;
+                if (p + 3 <= n) key = (hash3(own.x) << 6) | (uint32_t)lane;
                 key = wave_sort64(key);
                 {
                     const uint32_t kp = __shfl_up(key, 1, 64), kn = __shfl_down(key, 1, 64);
@@ -776,7 +778,6 @@ zgpu_deflate_kernel(Params P) {
                         const uint32_t stop = cmpmax < (uint32_t)P.nice ? cmpmax : (uint32_t)P.nice;
                         if (p + 3 <= n) {
                             uint32_t c = prevt[p & WMASK];
-                            const v4u own = ld16(ring + pi);
                             uint32_t last = 0;
                             for (int budget = P.max_chain; budget > 0; --budget) {
                                 const uint32_t dist = (p - c) & 0xffffu;
