@@ -149,11 +149,19 @@ __device__ inline void load_ring(uint8_t *ring, const uint8_t *in, uint32_t lo, 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 __device__ inline uint32_t ld4(const uint8_t *p) { return *(const u32_unaligned *)p; }
 
-// 16 bytes at any LDS address in one instruction, and the number of leading
-// bytes (0..16) in which two such pieces agree
+// 16 bytes at any LDS address, and the number of leading bytes (0..16) in which
+// two such pieces agree.  An LDS access that is not naturally aligned to its
+// width is served one lane per cycle (64 cycles per wave instruction, measured:
+// tools/lds_unaligned_bench.hip) against 7-11 cycles for aligned random reads,
+// so the 16 bytes come as five aligned dwords and are shifted into place.
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-typedef v4u __attribute__((aligned(1))) v4u_unaligned;
-__device__ inline v4u ld16(const uint8_t *p) { return *(const v4u_unaligned *)p; }
+__device__ inline v4u ld16(const uint8_t *ring, uint32_t idx) {
+    const uint32_t *w = (const uint32_t *)(ring + (idx & ~3u));
+    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
+    const uint32_t r = idx & 3u;
+    return v4u{__builtin_amdgcn_alignbyte(d1, d0, r), __builtin_amdgcn_alignbyte(d2, d1, r),
+               __builtin_amdgcn_alignbyte(d3, d2, r), __builtin_amdgcn_alignbyte(d4, d3, r)};
+}
 __device__ inline uint32_t mlen16(v4u a, v4u b) {
     const v4u x = a ^ b;
     const uint64_t lo = (uint64_t)x.x | ((uint64_t)x.y << 32), hi = (uint64_t)x.z | ((uint64_t)x.w << 32);
@@ -738,7 +746,7 @@ zgpu_deflate_kernel(Params P) {
                 PH_END(8);
                 // ---- insert: sort (hash, lane) in registers, link chains in item order ----
                 // this position's first 16 bytes: hashed here, compared against candidates below
-                const v4u own = ld16(ring + (p & (RING - 1)));
+                const v4u own = ld16(ring, p & (RING - 1));
                 uint32_t key = 0xffffffffu;
                 if (p + 3 <= n) key = (hash3(own.x) << 6) | (uint32_t)lane;
                 key = wave_sort64(key);
@@ -785,9 +793,9 @@ zgpu_deflate_kernel(Params P) {
                                 last = dist;
                                 const uint32_t ci = c & (RING - 1);
                                 const uint32_t nxt = prevt[c & WMASK];
-                                uint32_t len = mlen16(own, ld16(ring + ci));
+                                uint32_t len = mlen16(own, ld16(ring, ci));
                                 if (len == 16 && cmpmax > 16)
-                                    len = 16 + mlen16(ld16(ring + pi + 16), ld16(ring + ci + 16));
+                                    len = 16 + mlen16(ld16(ring, pi + 16), ld16(ring, ci + 16));
                                 if (len > cmpmax) len = cmpmax;
                                 if (len > blen) {
                                     blen = len;
