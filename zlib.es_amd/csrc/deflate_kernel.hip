@@ -162,12 +162,21 @@ __device__ inline v4u ld16(const uint8_t *ring, uint32_t idx) {
     return v4u{__builtin_amdgcn_alignbyte(d1, d0, r), __builtin_amdgcn_alignbyte(d2, d1, r),
                __builtin_amdgcn_alignbyte(d3, d2, r), __builtin_amdgcn_alignbyte(d4, d3, r)};
 }
+// index of the lowest set bit, 0xffffffff for 0 (one instruction, no zero test)
+__device__ inline uint32_t ffbl(uint32_t x) {
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 __device__ inline uint32_t mlen16(v4u a, v4u b) {
     const v4u x = a ^ b;
-    const uint64_t lo = (uint64_t)x.x | ((uint64_t)x.y << 32), hi = (uint64_t)x.z | ((uint64_t)x.w << 32);
-    if (lo) return (uint32_t)__builtin_ctzll(lo) >> 3;
-    if (hi) return 8u + ((uint32_t)__builtin_ctzll(hi) >> 3);
-    return 16u;
+    // straight-line: the first differing bit over the four words, 0xffffffff if none
+    const uint32_t f0 = ffbl(x.x), f1 = ffbl(x.y) | 32u, f2 = ffbl(x.z) | 64u, f3 = ffbl(x.w) | 96u;
+    uint32_t m = f0 < f1 ? f0 : f1;
+    m = m < f2 ? m : f2;
+    m = m < f3 ? m : f3;
+    m >>= 3;
+    return m < 16u ? m : 16u;
 }
 
 __device__ inline uint32_t hash3(uint32_t w) {
