@@ -187,6 +187,7 @@ def main():
                            "traffic": measured_traffic(nu, ub, args),
                            "kernel": "zgpu_deflate_kernel + zgpu_emit_kernel", "kernel_ms": round(k_ms, 3),
                            "search_kernel_ms": round(search_ms, 3), "emit_kernel_ms": round(emit_ms, 3)}
+        res.update(verify_all(data, in_off, out, out_off, dev))
         if world == 1 and not args.no_cpu:
             res.update(cpu_leg(args, data, out, out_off, nu, ub))
         print(json.dumps(res), flush=True)
@@ -206,6 +207,21 @@ def measured_traffic(nu, ub, args):
     if (w.get("units"), w.get("unit_bytes"), w.get("ctype"), w.get("lazy")) != (nu, ub, args.ctype, args.lazy):
         return None
     return t.get("bytes_per_launch")
+
+
+def verify_all(data, in_off, out, out_off, dev):
+    """Every unit of the batch through the GPU round-trip verifier (a strict DEFLATE decoder
+    that compares with the input as it goes; test infrastructure, outside the timed region)."""
+    try:
+        import _gpu_verify as gv
+        t0 = time.perf_counter()
+        st = gv.verify(out, torch.from_numpy(out_off.astype(np.int64)).to(dev), data,
+                       torch.from_numpy(in_off.astype(np.int64)).to(dev), True)
+        bad = int((st != 0).sum())
+        return {"roundtrip_all_units": bad == 0, "units_verified_on_gpu": int(st.numel()), "units_failed": bad,
+                "verify_ms": round((time.perf_counter() - t0) * 1e3, 1)}
+    except OSError as e:  # the verifier library is optional for the timing itself
+        return {"roundtrip_all_units": None, "verify_error": str(e)}
 
 
 def cpu_leg(args, data, out, out_off, nu, ub):
