@@ -229,10 +229,10 @@ __device__ inline void bitonic_sort(uint32_t *a, int n) {
     }
 }
 
-// Wave-to-wave hand-off through one LDS word.  LDS operations of a wave are
-// issued and completed in order and the LDS is a single coherent memory for
-// the workgroup, so a wave that has drained its own LDS queue (lgkmcnt(0)) may
-// publish, and a wave that has seen the value may read what was written before
+// Wave-to-wave hand-off through one LDS word.  The LDS executes a wave's
+// instructions in issue order and is a single coherent memory for the
+// workgroup, so a flag written after other LDS writes of the same wave lands
+// after them, and a wave that has seen the flag may read what was written before
 // it.  Only LDS is ordered here: no global-memory fence is involved.
 // The words are accessed through explicit LDS-address-space pointers: a volatile
 // access through a generic pointer would be issued as a (much slower) flat
@@ -249,7 +249,9 @@ __device__ inline void lds_wait_ge(uint32_t *word, uint32_t want) {
     asm volatile("" ::: "memory");
 }
 __device__ inline void lds_publish(uint32_t *word, uint32_t value) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // The LDS executes a wave's instructions in issue order, so the flag lands after the
+    // wave's earlier LDS writes without waiting for them; the compiler must keep that order.
+    asm volatile("" ::: "memory");
     if ((threadIdx.x & 63) == 0) lds_st(word, value);
 }
 
