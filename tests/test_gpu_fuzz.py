@@ -1,0 +1,68 @@
+"""Randomised batches through the whole GPU path, every unit checked on the
+device by the round-trip verifier and every requested checksum against the
+oracle: unit sizes from 0 to a few blocks, all content kinds, both Huffman
+modes, lazy settings, independent streams and chunked streams, several search
+depths.  The encoder's waves hand work to each other through LDS flags; a
+batch of a few thousand units of uneven sizes is what shakes that out."""
+import numpy as np
+import pytest
+import torch
+
+import _gpu_verify as gv
+import _oracle as zo
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ["text", "rndseq", "rnd", "runs", "seq", "small-alpha"]
+
+
+def _unit(rng, i):
+    kind = KINDS[int(rng.integers(0, len(KINDS)))]
+    r = rng.random()
+    if r < 0.15:
+        n = int(rng.integers(0, 70))
+    elif r < 0.6:
+        n = int(rng.integers(70, 20000))
+    elif r < 0.95:
+        n = int(rng.integers(20000, 140000))
+    else:
+        n = int(rng.integers(140000, 400000))
+    spec = {"gen": kind, "n": n, "seed": int(rng.integers(1, 1 << 30))}
+    if kind == "small-alpha":
+        spec["k"] = int(rng.integers(1, 5))
+    return zo.gen(spec)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_batches(seed):
+    import zlib_es_amd as z
+    N = z._native
+    rng = np.random.default_rng(seed)
+    datas = [_unit(rng, i) for i in range(600)]
+    origs = [d.tobytes() for d in datas]
+    flat = np.concatenate(datas)
+    off = np.zeros(len(datas) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([d.size for d in datas])
+    d_orig = torch.from_numpy(flat).cuda()
+    d_ooff = torch.from_numpy(off).cuda()
+    crc_ref = [zo.crc32(d) for d in datas[:50]]
+    adl_ref = [zo.adler32(d) for d in datas[:50]]
+    try:
+        for ctype, lazy, chain, chunked in [(2, 0, 8, False), (1, 0, 8, False), (2, 16, 3, False),
+                                            (2, 0, 32, True), (1, 7, 1, True)]:
+            z.set_search(chain, 258)
+            flags = (N.F_SYNC_ALIGN | N.F_FINAL_LAST) if chunked else N.F_FINAL_EACH
+            outs, crc, adl = z.deflate_batch(datas, ctype, lazy, flags=flags, want_crc=True, want_adler=True)
+            assert crc[:50] == crc_ref and adl[:50] == adl_ref
+            co = np.zeros(len(outs) + 1, dtype=np.int64)
+            co[1:] = np.cumsum([len(o) for o in outs])
+            d_comp = torch.from_numpy(np.frombuffer(b"".join(outs), dtype=np.uint8).copy()).cuda()
+            st = gv.verify(d_comp, torch.from_numpy(co).cuda(), d_orig, d_ooff, final_each=not chunked)
+            bad = [(i, gv.STATUS[int(s)], datas[i].size) for i, s in enumerate(st.tolist()) if s]
+            assert not bad, (ctype, lazy, chain, chunked, bad[:5])
+            if chunked:
+                stream = b"".join(outs)
+                assert zo.inflate_raw(stream, flat.size) == flat.tobytes()
+            assert all(len(o) <= z.deflate_bound(len(d)) for o, d in zip(outs, origs))
+    finally:
+        z.set_search(8, 258)
