@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--chain", type=int, default=0, help="hash-chain search depth (0 = library default)")
-    ap.add_argument("--nice", type=int, default=258)
+    ap.add_argument("--nice", type=int, default=32)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -75,6 +75,8 @@ int zo_inflate_zlib(const uint8_t *in, size_t n, uint8_t *out, size_t cap,
 int zo_gunzip(const uint8_t *in, size_t n, uint8_t *out, size_t cap,
               size_t *out_len);
 /* counts blocks by type while decoding a raw stream: counts[0..2] */
+/* literal and match token counts of the last zo_inflate_raw* call (diagnostics) */
+void zo_inflate_last_tokens(uint32_t out[2]);
 int zo_inflate_raw_stats(const uint8_t *in, size_t n, uint8_t *out, size_t cap,
                          size_t *out_len, size_t *in_used, uint32_t counts[3]);
 

@@ -99,6 +99,13 @@ static const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 
 static const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6,
                                  7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 
+/* token counts of the last decoded stream (diagnostics: tools/token_stats.py) */
+static uint32_t g_tok_lits, g_tok_matches;
+void zo_inflate_last_tokens(uint32_t out[2]) {
+    out[0] = g_tok_lits;
+    out[1] = g_tok_matches;
+}
+
 static int inflate_codes(zo_inf *s, const zo_huff *lc, const zo_huff *dc) {
     for (;;) {
         int sym;
@@ -107,6 +114,7 @@ static int inflate_codes(zo_inf *s, const zo_huff *lc, const zo_huff *dc) {
         if (sym < 256) {
             if (s->op >= s->cap) return ZO_E_OUTCAP;
             s->out[s->op++] = (uint8_t)sym;
+            g_tok_lits++;
         } else if (sym == 256)
             return 0;
         else {
@@ -116,6 +124,7 @@ static int inflate_codes(zo_inf *s, const zo_huff *lc, const zo_huff *dc) {
             e = get_bits(s, LEXT[sym], &x);
             if (e) return e;
             size_t len = LBASE[sym] + x;
+            g_tok_matches++;
             int ds;
             e = decode_sym(s, dc, &ds);
             if (e) return e;
@@ -229,6 +238,7 @@ int zo_inflate_raw_stats(const uint8_t *in, size_t n, uint8_t *out, size_t cap, 
     s.cap = cap;
     s.op = 0;
     if (counts) counts[0] = counts[1] = counts[2] = 0;
+    g_tok_lits = g_tok_matches = 0;
     int last, e;
     do {
         uint32_t v;

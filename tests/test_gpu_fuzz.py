@@ -48,9 +48,9 @@ def test_random_batches(seed):
     crc_ref = [zo.crc32(d) for d in datas[:50]]
     adl_ref = [zo.adler32(d) for d in datas[:50]]
     try:
-        for ctype, lazy, chain, chunked in [(2, 0, 8, False), (1, 0, 8, False), (2, 16, 3, False),
-                                            (2, 0, 32, True), (1, 7, 1, True)]:
-            z.set_search(chain, 258)
+        for ctype, lazy, chain, nice, chunked in [(2, 0, 8, 32, False), (1, 0, 8, 258, False), (2, 16, 3, 32, False),
+                                                  (2, 0, 32, 258, True), (1, 7, 1, 8, True)]:
+            z.set_search(chain, nice)
             flags = (N.F_SYNC_ALIGN | N.F_FINAL_LAST) if chunked else N.F_FINAL_EACH
             outs, crc, adl = z.deflate_batch(datas, ctype, lazy, flags=flags, want_crc=True, want_adler=True)
             assert crc[:50] == crc_ref and adl[:50] == adl_ref
@@ -59,10 +59,10 @@ def test_random_batches(seed):
             d_comp = torch.from_numpy(np.frombuffer(b"".join(outs), dtype=np.uint8).copy()).cuda()
             st = gv.verify(d_comp, torch.from_numpy(co).cuda(), d_orig, d_ooff, final_each=not chunked)
             bad = [(i, gv.STATUS[int(s)], datas[i].size) for i, s in enumerate(st.tolist()) if s]
-            assert not bad, (ctype, lazy, chain, chunked, bad[:5])
+            assert not bad, (ctype, lazy, chain, nice, chunked, bad[:5])
             if chunked:
                 stream = b"".join(outs)
                 assert zo.inflate_raw(stream, flat.size) == flat.tobytes()
             assert all(len(o) <= z.deflate_bound(len(d)) for o, d in zip(outs, origs))
     finally:
-        z.set_search(8, 258)
+        z.set_search(8, 32)

@@ -47,7 +47,7 @@ def run(name, data, nu, ub, ctype, lazy):
 def main():
     nu, ub = int(os.environ.get("NU", 2048)), int(os.environ.get("UB", 65536))
     if "CHAIN" in os.environ:  # default: the library's own search depth
-        z.set_search(int(os.environ["CHAIN"]), 258)
+        z.set_search(int(os.environ["CHAIN"]), int(os.environ.get("NICE", "32")))
     dev = torch.device("cuda")
     full = bench.gen_units(20 * 512, ub, 7, dev).view(-1, ub)
     kinds = {"text": (0, 10), "binary": (10, 15), "random": (15, 18), "lowent": (18, 20)}

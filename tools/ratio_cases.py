@@ -16,11 +16,12 @@ cases = [c for c in golden["cases"] if c["n"] >= 16384]
 datas = [zo.gen(c["spec"]) for c in cases]
 chains = [int(x) for x in os.environ.get("CHAINS", "8,16,32,128").split(",")]
 LAZY = int(os.environ.get("LAZY", "0"))
+NICE = int(os.environ.get("NICE", "32"))
 for ct in (1, 2):
     print("ctype", ct)
     rows = {}
     for ch in chains:
-        z.set_search(ch, 258)
+        z.set_search(ch, NICE)
         outs, _, _ = z.deflate_batch(datas, ct, LAZY)
         rows[ch] = [len(o) for o in outs]
     for i, c in enumerate(cases):

@@ -111,7 +111,7 @@ def deflate_bound(n):
     return int(lib().zgpu_deflate_bound(n))
 
 
-def set_search(max_chain, nice_length=258):
+def set_search(max_chain, nice_length=32):
     _check(lib().zgpu_set_search(max_chain, nice_length), "zgpu_set_search")
 
 

@@ -51,7 +51,8 @@ constexpr uint32_t LOOKAHEAD = 64 + 6 * 64 + 258 + 16;  // bytes an item may rea
 constexpr uint32_t REFILL = 16384;  // ring refill granule
 constexpr uint32_t CMP_CAP = 32;   // pass-1 compare length cap (bytes)
 constexpr uint32_t SHARE_MIN = 16;  // matches at least this long offer their distance to the wave
-constexpr int SHARE_ITERS = 6;      // distinct distances scored per wave
+constexpr int SHARE_ITERS = 6;      // distinct distances scored per wave ...
+constexpr int SHARE_ITERS_THOROUGH = 16;  // ... and when the walk goes on past the first capped candidate
 
 constexpr uint32_t huf_scratch_bytes(uint32_t cap) { return 17 * cap + 128; }  // see HufS
 
@@ -524,10 +525,10 @@ struct Params {
     unsigned long long *prof;   // 16 phase counters (diagnostic builds) or null
 };
 
-}  // namespace
-
-extern "C" __global__ void __launch_bounds__(WG)
-zgpu_deflate_kernel(Params P) {
+// THOROUGH: the chain walk goes on past candidates that reach the compare cap and
+// pass 2 settles which of them runs longest (chosen by nice_length > CMP_CAP).
+template <bool THOROUGH>
+__device__ __forceinline__ void search_units(const Params &P) {
     __shared__ __align__(16) uint8_t lds_raw[L_TOTAL];
     Lds L{lds_raw};
     const int tid = threadIdx.x, lane = tid & 63;
@@ -785,6 +786,7 @@ zgpu_deflate_kernel(Params P) {
                     const uint32_t maxlen = p < n ? ((n - p) < 258u ? (n - p) : 258u) : 0u;
                     const uint32_t limit = p < MAXDIST ? p : MAXDIST;
                     uint32_t blen = 2;
+                    uint32_t ex0 = 0, ex1 = 0, ex2 = 0;  // further candidates that reached the compare cap
                     {
                         // pass 1, lane per position: walk the hash chain.  A candidate costs one
                         // LDS round trip: its chain link and its first 16 bytes (one unaligned
@@ -794,7 +796,6 @@ zgpu_deflate_kernel(Params P) {
                         // more (CMP_CAP; pass 2 finds the exact length of long matches).
                         const uint32_t pi = p & (RING - 1);
                         const uint32_t cmpmax = maxlen < CMP_CAP ? maxlen : CMP_CAP;
-                        const uint32_t stop = cmpmax < (uint32_t)P.nice ? cmpmax : (uint32_t)P.nice;
                         if (p + 3 <= n) {
                             uint32_t c = prevt[p & WMASK];
                             uint32_t last = 0;
@@ -811,7 +812,21 @@ zgpu_deflate_kernel(Params P) {
                                 if (len > blen) {
                                     blen = len;
                                     best_dist = dist;
-                                    if (len >= stop) break;
+                                    // as long as the unit allows, or as long as the caller finds nice
+                                    // (nice <= CMP_CAP, the default: the first capped candidate ends
+                                    // the walk; beyond it the walk goes on and collects the others)
+                                    if (len >= maxlen || len >= (uint32_t)P.nice) break;
+                                } else if (THOROUGH && len == CMP_CAP) {
+                                    // another candidate that reached the compare cap: which of them
+                                    // runs longest is settled in pass 2
+                                    if (!ex0)
+                                        ex0 = dist;
+                                    else if (!ex1)
+                                        ex1 = dist;
+                                    else {
+                                        ex2 = dist;
+                                        break;
+                                    }
                                 }
                                 c = nxt;
                             }
@@ -823,11 +838,29 @@ zgpu_deflate_kernel(Params P) {
                         // lane a long match is scored for all 64 positions at once -- one byte
                         // compare per lane, a ballot, and count-trailing-ones give every lane
                         // its exact match length (up to 258) at that distance.
+                        // Offers: every lane's best distance if it is long enough to be worth
+                        // sharing, and the other candidates that reached the compare cap.
                         const uint32_t offer = best_dist;
+                        constexpr int share_iters = THOROUGH ? SHARE_ITERS_THOROUGH : SHARE_ITERS;
                         unsigned long long todo = __ballot(blen >= SHARE_MIN);
-                        for (int it = 0; it < SHARE_ITERS && todo; ++it) {
-                            const int src = __builtin_ctzll(todo);
-                            const uint32_t d = (uint32_t)__shfl((int)offer, src, 64);
+                        unsigned long long todo0 = 0, todo1 = 0, todo2 = 0;
+                        if (THOROUGH) {
+                            todo0 = __ballot(ex0 != 0);
+                            todo1 = __ballot(ex1 != 0);
+                            todo2 = __ballot(ex2 != 0);
+                        }
+                        for (int it = 0; it < share_iters; ++it) {
+                            uint32_t d;
+                            if (todo)
+                                d = (uint32_t)__shfl((int)offer, __builtin_ctzll(todo), 64);
+                            else if (THOROUGH && todo0)
+                                d = (uint32_t)__shfl((int)ex0, __builtin_ctzll(todo0), 64);
+                            else if (THOROUGH && todo1)
+                                d = (uint32_t)__shfl((int)ex1, __builtin_ctzll(todo1), 64);
+                            else if (THOROUGH && todo2)
+                                d = (uint32_t)__shfl((int)ex2, __builtin_ctzll(todo2), 64);
+                            else
+                                break;
                             uint32_t run = 0;
                             bool open = true;
                             for (uint32_t w = 0; w < 6; ++w) {
@@ -853,6 +886,11 @@ zgpu_deflate_kernel(Params P) {
                                 best_dist = d;
                             }
                             todo &= ~__ballot(offer == d);
+                            if (THOROUGH) {
+                                todo0 &= ~__ballot(ex0 == d);
+                                todo1 &= ~__ballot(ex1 == d);
+                                todo2 &= ~__ballot(ex2 == d);
+                            }
                         }
                     }
                     if (blen >= 3 && !(blen == 3 && best_dist > 4096)) best_len = blen;
@@ -909,6 +947,11 @@ zgpu_deflate_kernel(Params P) {
 #endif
     }
 }
+
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(WG) zgpu_deflate_kernel(Params P) { search_units<false>(P); }
+extern "C" __global__ void __launch_bounds__(WG) zgpu_deflate_thorough_kernel(Params P) { search_units<true>(P); }
 
 namespace {
 

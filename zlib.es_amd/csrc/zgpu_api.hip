@@ -19,7 +19,7 @@ namespace {
 
 thread_local int g_last_hip = 0;
 int g_max_chain = 8;
-int g_nice = 258;
+int g_nice = 32;
 int g_min_lazy = 258;  // the parse always looks one position ahead unless told otherwise
 unsigned long long *g_prof = nullptr;  // diagnostic builds only
 
@@ -379,7 +379,10 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             P.nice = g_nice;
             P.prof = g_prof;
             const int sgrid = (int)(cnt < (uint32_t)p->ds->cus ? cnt : (uint32_t)p->ds->cus);
-            hipLaunchKernelGGL(zgpu_deflate_kernel, dim3(sgrid), dim3(1024), 0, st, P);
+            if (g_nice > 32)
+                hipLaunchKernelGGL(zgpu_deflate_thorough_kernel, dim3(sgrid), dim3(1024), 0, st, P);
+            else
+                hipLaunchKernelGGL(zgpu_deflate_kernel, dim3(sgrid), dim3(1024), 0, st, P);
             if (r == 0) HIPCHK(hipEventRecord(p->ev[4], st));
             EParams E;
             E.in_off = p->d_in_off;
