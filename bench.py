@@ -273,7 +273,9 @@ def bench_checksum(args, z, dev, rank, world, dist, barrier):
            "config": {"workload": "CRC32 + Adler32 over %d random bytes per GPU" % nbytes},
            "roofline": {"bound": "hbm", "achieved": round(nbytes / (k_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                        "traffic": None, "kernel": "zgpu_checksum_kernel", "kernel_ms": round(k_ms, 3)}}
+                        "traffic": None,
+                        "kernel": "zgpu_checksum_wide_kernel" if nbytes >= (64 << 20) else "zgpu_checksum_kernel",
+                        "kernel_ms": round(k_ms, 3)}}
     if rank == 0 and world == 1 and not args.no_cpu:
         import _oracle as zo
         n = min(nbytes, 256 << 20)

@@ -17,6 +17,8 @@ RATIO_BAR = 1.03
 
 @pytest.fixture(scope="module")
 def z():
+    import torch
+    torch.cuda.init()  # device tensors are used below; let torch open the device before the library does
     import zlib_es_amd
     return zlib_es_amd
 
@@ -36,6 +38,22 @@ def test_checksum_sizes_and_alignments(z):
         for a in (0, 1, 5, 13):
             d = base[a:a + n]
             assert z.checksum(d) == (zo.crc32(d), zo.adler32(d)), (n, a)
+
+
+def test_checksum_large_buffers(z):
+    # buffers of 64 MiB and more take the wide kernel (11-bit tables, 4 MiB segments)
+    import torch
+    d = zo.gen({"gen": "rnd", "n": 64 << 20, "seed": 9})
+    assert (zo.crc32(d), zo.adler32(d)) == (0xA02E0F19, 0xD50B8ECB)  # the reference's values for this input
+    t = torch.from_numpy(d).cuda()
+    assert z._native.checksum_device(t.data_ptr(), d.size) == (0xA02E0F19, 0xD50B8ECB)
+    rng = np.random.default_rng(3)
+    big = rng.integers(0, 256, (150 << 20) + 64, dtype=np.uint8)
+    big[: 8 << 20] = 0xFF  # long runs of one value stress the Adler sums
+    tb = torch.from_numpy(big).cuda()
+    for a, n in ((0, 150 << 20), (1, (64 << 20) + 1), (7, (100 << 20) + 12345), (15, (64 << 20) + 63), (3, (68 << 20) - 3)):
+        want = (zo.crc32(big[a:a + n]), zo.adler32(big[a:a + n]))
+        assert z._native.checksum_device(tb.data_ptr() + a, n) == want, (a, n)
 
 
 def test_checksum_golden_cases(z, golden):

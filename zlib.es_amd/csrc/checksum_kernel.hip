@@ -175,3 +175,151 @@ zgpu_checksum_kernel(const uint8_t *in, const uint64_t *seg_off, uint32_t n_segs
         __syncthreads();
     }
 }
+
+// ---- wide variant for large buffers -------------------------------------------
+// The kernel above is bound by its LDS lookups (20 per 16 bytes, ~7 LDS cycles
+// each at random addresses).  This variant indexes its tables with 11 bits
+// instead of 8: 12 lookups for the 128 bits of a piece + 3 to advance the 32-bit
+// remainder = 15.  The tables (15 x 2048 words, 120 KB) fill the LDS of a CU, so
+// one 1024-thread workgroup runs per CU and every lane keeps the next piece in
+// flight while it folds the current one.
+// tables: [0..12*2048) W_k[v] = remainder contributed by bits [11k, 11k+11) of a
+// piece; [12*2048..15*2048) S_c[v] = (v << 11c) advanced by 16*1024 bytes;
+// then x^(128*2^lv) for lv = 0..9; then the 256-entry byte table.
+extern "C" __global__ void __launch_bounds__(ZGPU_CKW_THREADS)
+zgpu_checksum_wide_kernel(const uint8_t *in, const uint64_t *seg_off, uint32_t n_segs,
+                          const uint32_t *tables, uint32_t *out_crc, uint32_t *out_adler) {
+    constexpr int TW = ZGPU_CKW_THREADS;
+    __shared__ uint32_t tab[15 * 2048];
+    __shared__ uint32_t xpow[10];
+    __shared__ uint32_t bytetab[256];
+    __shared__ uint32_t red_crc[TW / 64];
+    __shared__ unsigned long long red_sb[TW / 64], red_sw[TW / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 15 * 2048; i += TW) tab[i] = tables[i];
+    if (tid < 10) xpow[tid] = tables[15 * 2048 + tid];
+    if (tid < 256) bytetab[tid] = tables[15 * 2048 + 10 + tid];
+    __syncthreads();
+    const uint32_t *S = tab + 12 * 2048;
+
+    for (uint32_t sg = blockIdx.x; sg < n_segs; sg += gridDim.x) {
+        const uint64_t o = seg_off[sg], n = seg_off[sg + 1] - o;
+        const uint8_t *p0 = in + o;
+        uint32_t crc_state = 0xffffffffu;
+        unsigned long long sb = 0, sw = 0;  // sum b, sum q*b
+        uint64_t tail_lo = 0, tail_hi = n;  // byte range finished serially by thread 0
+        if (n >= 64) {
+            const uint32_t a = (uint32_t)((uintptr_t)p0 & 15u);
+            const uint8_t *vstart = p0 - a;
+            const uint64_t kv = (a + n) >> 4;  // full 16-byte pieces (the first may start before p0)
+            const uint32_t pad = (uint32_t)((TW - (kv % TW)) % TW);
+            const uint64_t rounds = (kv + pad) / TW;
+            uint32_t A = 0;
+            auto fetch = [&](uint64_t r) -> uint4 {
+                const int64_t i = (int64_t)(r * TW + tid) - (int64_t)pad;
+                return i >= 0 ? *(const uint4 *)(vstart + 16 * (uint64_t)i) : make_uint4(0, 0, 0, 0);
+            };
+            // three pieces per lane in flight: 48 KiB per CU, enough to cover the HBM latency
+            uint4 cur = fetch(0);
+            uint4 nxt = rounds > 1 ? fetch(1) : make_uint4(0, 0, 0, 0);
+            for (uint64_t r = 0; r < rounds; ++r) {
+                const uint4 nxt2 = r + 2 < rounds ? fetch(r + 2) : make_uint4(0, 0, 0, 0);
+                const int64_t i = (int64_t)(r * TW + tid) - (int64_t)pad;
+                // advance by 16*TW bytes
+                A = S[A & 0x7ffu] ^ S[2048 + ((A >> 11) & 0x7ffu)] ^ S[4096 + (A >> 22)];
+                if (i >= 0) {
+                    uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+                    const int64_t q0 = 16 * i - (int64_t)a;  // segment index of byte 0
+                    const uint32_t s = dot4(w[0], 0x01010101u, dot4(w[1], 0x01010101u,
+                                       dot4(w[2], 0x01010101u, dot4(w[3], 0x01010101u, 0))));
+                    const uint32_t j = dot4(w[0], 0x03020100u, dot4(w[1], 0x07060504u,
+                                       dot4(w[2], 0x0b0a0908u, dot4(w[3], 0x0f0e0d0cu, 0))));
+                    if (i < 2) {
+                        // zero the bytes before the segment (Adler and CRC both skip them); fold
+                        // the CRC preset into bytes 0..3 of the segment
+                        uint32_t xr[4] = {0, 0, 0, 0};
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            const int64_t q = q0 + k;
+                            if (q < 0) w[k >> 2] &= ~(0xffu << (8 * (k & 3)));
+                            if (q >= 0 && q < 4) xr[k >> 2] |= 0xffu << (8 * (k & 3));
+                        }
+                        const uint32_t s2 = dot4(w[0], 0x01010101u, dot4(w[1], 0x01010101u,
+                                            dot4(w[2], 0x01010101u, dot4(w[3], 0x01010101u, 0))));
+                        const uint32_t j2 = dot4(w[0], 0x03020100u, dot4(w[1], 0x07060504u,
+                                            dot4(w[2], 0x0b0a0908u, dot4(w[3], 0x0f0e0d0cu, 0))));
+                        sb += s2;
+                        sw += (unsigned long long)((long long)q0 * (long long)s2 + (long long)j2);
+                        w[0] ^= xr[0];
+                        w[1] ^= xr[1];
+                        w[2] ^= xr[2];
+                        w[3] ^= xr[3];
+                    } else {
+                        sb += s;
+                        sw += (unsigned long long)q0 * s + j;
+                    }
+                    // the 128 bits of the piece, 11 at a time
+                    const uint32_t c2 = __builtin_amdgcn_alignbit(w[1], w[0], 22) & 0x7ffu;
+                    const uint32_t c5 = __builtin_amdgcn_alignbit(w[2], w[1], 23) & 0x7ffu;
+                    const uint32_t c8 = __builtin_amdgcn_alignbit(w[3], w[2], 24) & 0x7ffu;
+                    A ^= tab[0 * 2048 + (w[0] & 0x7ffu)] ^ tab[1 * 2048 + ((w[0] >> 11) & 0x7ffu)] ^
+                         tab[2 * 2048 + c2] ^ tab[3 * 2048 + ((w[1] >> 1) & 0x7ffu)] ^
+                         tab[4 * 2048 + ((w[1] >> 12) & 0x7ffu)] ^ tab[5 * 2048 + c5] ^
+                         tab[6 * 2048 + ((w[2] >> 2) & 0x7ffu)] ^ tab[7 * 2048 + ((w[2] >> 13) & 0x7ffu)] ^
+                         tab[8 * 2048 + c8] ^ tab[9 * 2048 + ((w[3] >> 3) & 0x7ffu)] ^
+                         tab[10 * 2048 + ((w[3] >> 14) & 0x7ffu)] ^ tab[11 * 2048 + (w[3] >> 25)];
+                }
+                cur = nxt;
+                nxt = nxt2;
+            }
+            // fold the lane remainders: lane t must be advanced by 16*(TW-1-t) bytes
+#pragma unroll
+            for (int d = 1, lv = 0; d < 64; d <<= 1, ++lv) {
+                const uint32_t other = __shfl_down(A, d, 64);
+                if ((lane & (2 * d - 1)) == 0) A = gf_mul(A, xpow[lv]) ^ other;
+            }
+            if (lane == 0) red_crc[wave] = A;
+            __syncthreads();
+            if (wave == 0) {
+                uint32_t B = lane < TW / 64 ? red_crc[lane] : 0u;
+#pragma unroll
+                for (int d = 1, lv = 6; d < TW / 64; d <<= 1, ++lv) {
+                    const uint32_t other = __shfl_down(B, d, 64);
+                    if ((lane & (2 * d - 1)) == 0) B = gf_mul(B, xpow[lv]) ^ other;
+                }
+                if (lane == 0) crc_state = B;
+            }
+            tail_lo = kv * 16 - a;
+        }
+        // Adler partial sums across the workgroup
+        for (int d = 32; d > 0; d >>= 1) {
+            sb += __shfl_down(sb, d, 64);
+            sw += __shfl_down(sw, d, 64);
+        }
+        if (lane == 0) {
+            red_sb[wave] = sb;
+            red_sw[wave] = sw;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long tsb = 0, tsw = 0;
+            for (int w = 0; w < TW / 64; ++w) {
+                tsb += red_sb[w];
+                tsw += red_sw[w];
+            }
+            uint32_t c = crc_state;
+            for (uint64_t q = tail_lo; q < tail_hi; ++q) {
+                const uint32_t b = p0[q];
+                c = (c >> 8) ^ bytetab[(c ^ b) & 0xff];
+                tsb += b;
+                tsw += q * b;
+            }
+            out_crc[sg] = c ^ 0xffffffffu;
+            const unsigned long long nm = n % ADLER_MOD, bm = tsb % ADLER_MOD, wm = tsw % ADLER_MOD;
+            const uint32_t s1 = (uint32_t)((1 + bm) % ADLER_MOD);
+            const uint32_t s2 = (uint32_t)((nm + nm * bm + (ADLER_MOD - wm)) % ADLER_MOD);
+            out_adler[sg] = (s2 << 16) | s1;
+        }
+        __syncthreads();
+    }
+}

@@ -59,6 +59,7 @@ struct DeviceState {
     int device = -1;
     int cus = 0;
     uint32_t *d_tables = nullptr;  // checksum kernel tables
+    uint32_t *d_tables_wide = nullptr;  // 11-bit tables of the wide checksum kernel
     // scratch for zgpu_checksum_device
     uint64_t *d_seg_off = nullptr;
     uint32_t *d_seg_crc = nullptr, *d_seg_adler = nullptr;
@@ -88,6 +89,29 @@ void build_tables(std::vector<uint32_t> &t) {
     for (int lv = 0; lv < 8; ++lv) t[20 * 256 + lv] = h_xpow_bytes(16ull << lv);
 }
 
+// tables of zgpu_checksum_wide_kernel, derived from the byte-sliced ones by linearity
+void build_tables_wide(const std::vector<uint32_t> &t, std::vector<uint32_t> &w) {
+    w.assign(15 * 2048 + 10 + 256, 0);
+    // remainder contributed by bit j of a 16-byte piece: byte j/8 followed by 15 - j/8 more bytes
+    uint32_t unit[128];
+    for (int j = 0; j < 128; ++j) unit[j] = t[(15 - j / 8) * 256 + (1u << (j % 8))];
+    for (int k = 0; k < 12; ++k)
+        for (uint32_t v = 0; v < 2048; ++v) {
+            uint32_t x = 0;
+            for (int b = 0; b < 11 && 11 * k + b < 128; ++b)
+                if (v >> b & 1) x ^= unit[11 * k + b];
+            w[k * 2048 + v] = x;
+        }
+    const uint32_t adv = h_xpow_bytes(16ull * ZGPU_CKW_THREADS);
+    for (int c = 0; c < 3; ++c)
+        for (uint32_t v = 0; v < 2048; ++v) {
+            const uint64_t sh = (uint64_t)v << (11 * c);
+            w[(12 + c) * 2048 + v] = sh >> 32 ? 0u : h_gf_mul((uint32_t)sh, adv);
+        }
+    for (int lv = 0; lv < 10; ++lv) w[15 * 2048 + lv] = h_xpow_bytes(16ull << lv);
+    for (int i = 0; i < 256; ++i) w[15 * 2048 + 10 + i] = t[i];
+}
+
 int get_state(DeviceState **out) {
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
@@ -107,6 +131,10 @@ int get_state(DeviceState **out) {
     build_tables(t);
     HIPCHK(hipMalloc(&s->d_tables, t.size() * 4));
     HIPCHK(hipMemcpy(s->d_tables, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    std::vector<uint32_t> tw;
+    build_tables_wide(t, tw);
+    HIPCHK(hipMalloc(&s->d_tables_wide, tw.size() * 4));
+    HIPCHK(hipMemcpy(s->d_tables_wide, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipEventCreate(&s->ev0));
     HIPCHK(hipEventCreate(&s->ev1));
     g_devs.push_back(s);
@@ -168,6 +196,7 @@ void zgpu_shutdown(void) {
     for (auto *s : g_devs) {
         (void)hipSetDevice(s->device);
         (void)hipFree(s->d_tables);
+        (void)hipFree(s->d_tables_wide);
         (void)hipFree(s->d_seg_off);
         (void)hipFree(s->d_seg_crc);
         (void)hipFree(s->d_seg_adler);
@@ -527,7 +556,10 @@ int zgpu_checksum_device(const void *d_in, uint64_t len, uint32_t *crc32, uint32
     int rc = get_state(&ds);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream_;
-    const uint64_t nseg = len ? (len + ZGPU_CK_SEG - 1) / ZGPU_CK_SEG : 1;
+    // large buffers go through the wide kernel (one workgroup per CU, 4 MiB segments)
+    const bool wide = len >= ZGPU_CKW_MIN_BYTES;
+    const uint64_t seg = wide ? ZGPU_CKW_SEG : ZGPU_CK_SEG;
+    const uint64_t nseg = len ? (len + seg - 1) / seg : 1;
     if (nseg + 1 > ds->seg_cap) {
         (void)hipFree(ds->d_seg_off);
         (void)hipFree(ds->d_seg_crc);
@@ -539,15 +571,22 @@ int zgpu_checksum_device(const void *d_in, uint64_t len, uint32_t *crc32, uint32
         ds->seg_cap = nseg + 1;
     }
     std::vector<uint64_t> off(nseg + 1);
-    for (uint64_t i = 0; i < nseg; ++i) off[i] = i * (uint64_t)ZGPU_CK_SEG;
+    for (uint64_t i = 0; i < nseg; ++i) off[i] = i * seg;
     off[nseg] = len;
     HIPCHK(hipMemcpyAsync(ds->d_seg_off, off.data(), (nseg + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));  // off is a local
-    const int grid = (int)(nseg < (uint64_t)ds->cus * 8 ? nseg : (uint64_t)ds->cus * 8);
     HIPCHK(hipEventRecord(ds->ev0, st));
-    hipLaunchKernelGGL(zgpu_checksum_kernel, dim3(grid), dim3(ZGPU_CK_THREADS), 0, st,
-                       (const uint8_t *)d_in, ds->d_seg_off, (uint32_t)nseg, ds->d_tables,
-                       ds->d_seg_crc, ds->d_seg_adler);
+    if (wide) {
+        const int grid = (int)(nseg < (uint64_t)ds->cus ? nseg : (uint64_t)ds->cus);
+        hipLaunchKernelGGL(zgpu_checksum_wide_kernel, dim3(grid), dim3(ZGPU_CKW_THREADS), 0, st,
+                           (const uint8_t *)d_in, ds->d_seg_off, (uint32_t)nseg, ds->d_tables_wide,
+                           ds->d_seg_crc, ds->d_seg_adler);
+    } else {
+        const int grid = (int)(nseg < (uint64_t)ds->cus * 8 ? nseg : (uint64_t)ds->cus * 8);
+        hipLaunchKernelGGL(zgpu_checksum_kernel, dim3(grid), dim3(ZGPU_CK_THREADS), 0, st,
+                           (const uint8_t *)d_in, ds->d_seg_off, (uint32_t)nseg, ds->d_tables,
+                           ds->d_seg_crc, ds->d_seg_adler);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ds->ev1, st));
     std::vector<uint32_t> c(nseg), a(nseg);
@@ -556,10 +595,10 @@ int zgpu_checksum_device(const void *d_in, uint64_t len, uint32_t *crc32, uint32
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipEventElapsedTime(&ds->last_ck_ms, ds->ev0, ds->ev1));
     uint32_t crc = c[0], ad = a[0];
-    const uint32_t xs = h_xpow_bytes(ZGPU_CK_SEG);
+    const uint32_t xs = h_xpow_bytes(seg);
     for (uint64_t i = 1; i < nseg; ++i) {
         const uint64_t l = off[i + 1] - off[i];
-        crc = h_gf_mul(crc, l == ZGPU_CK_SEG ? xs : h_xpow_bytes(l)) ^ c[i];
+        crc = h_gf_mul(crc, l == seg ? xs : h_xpow_bytes(l)) ^ c[i];
         ad = zgpu_adler32_combine(ad, a[i], l);
     }
     if (crc32) *crc32 = crc;

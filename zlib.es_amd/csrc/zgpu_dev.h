@@ -15,3 +15,7 @@
 // checksum kernel geometry: every workgroup folds ZGPU_CK_SEG bytes
 #define ZGPU_CK_THREADS 256
 #define ZGPU_CK_SEG (1u << 20)
+// wide checksum kernel (large buffers): one 1024-thread workgroup per CU, 4 MiB segments
+#define ZGPU_CKW_THREADS 1024
+#define ZGPU_CKW_SEG (4u << 20)
+#define ZGPU_CKW_MIN_BYTES (64ull << 20)
