@@ -113,13 +113,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path to time)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; ZGPU_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with
+    # fewer GPUs than ranks (ranks then share devices and the reductions run on the CPU)
+    backend = os.environ.get("ZGPU_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ndev:
+        raise SystemExit("rank %d has no GPU of its own (%d visible)" % (local_rank, ndev))
+    local_dev = local_rank % ndev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     import zlib_es_amd as z
     N = z._native
@@ -159,8 +170,8 @@ def main():
     out_bytes = int(out_off[-1])
     in_bytes = nu * ub
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    tot_in = torch.tensor([float(in_bytes)], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    tot_in = torch.tensor([float(in_bytes)], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot_in, op=dist.ReduceOp.SUM)
