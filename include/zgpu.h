@@ -46,6 +46,12 @@ enum {
      * (chunked Gzip/Deflate bodies around src/gzip.js:107-111) */
     ZGPU_F_SYNC_ALIGN = 2u,
     ZGPU_F_FINAL_LAST = 4u,
+    /* with ZGPU_F_SYNC_ALIGN: a unit's matches may reach up to 32 KiB back into
+     * the units before it (they are contiguous in `in`), as a decoder of the
+     * concatenated stream allows; the chunks then compress like one stream
+     * compressed in one piece (the reference keeps its whole window,
+     * src/rawdeflate.js:325-327) */
+    ZGPU_F_PRIME_WINDOW = 8u,
     /* also compute per-unit CRC-32 / Adler-32 of the unit's INPUT
      * (CRC32.calc src/crc32.js:14, Adler32.mkHash src/adler32.js:11) */
     ZGPU_F_WANT_CRC = 16u,

@@ -36,7 +36,9 @@ enum {
 
 /* flags: bit 0 = every unit must end with BFINAL (independent streams);
  * otherwise a unit must end with an empty stored block (chunk of one stream)
- * except the last, which must end with BFINAL.
+ * except the last, which must end with BFINAL.  bit 1 = the units are
+ * consecutive pieces of one buffer and a unit's matches may reach back into
+ * the pieces before it (window priming).
  * All pointers are device pointers; comp_off / orig_off have n_units + 1
  * entries; status has n_units.  stream: hipStream_t (NULL = default).
  * Returns 0, or the negated hipError_t of a failed launch. */

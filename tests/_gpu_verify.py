@@ -23,13 +23,13 @@ def lib():
     return _lib
 
 
-def verify(comp, comp_off, orig, orig_off, final_each=True):
+def verify(comp, comp_off, orig, orig_off, final_each=True, primed=False):
     """comp / orig: uint8 CUDA tensors; comp_off / orig_off: int64 or uint64 CUDA tensors of
     n+1 byte offsets.  Returns the per-unit status as a CPU int tensor (0 = ok)."""
     n = comp_off.numel() - 1
     status = torch.full((n,), 99, dtype=torch.int32, device=comp.device)
     rc = lib().zgpu_verify_streams(comp.data_ptr(), comp_off.data_ptr(), orig.data_ptr(), orig_off.data_ptr(), n,
-                                   1 if final_each else 0, status.data_ptr(), None)
+                                   (1 if final_each else 0) | (2 if primed else 0), status.data_ptr(), None)
     if rc:
         raise RuntimeError("zgpu_verify_streams: hip error %d" % -rc)
     torch.cuda.synchronize()

@@ -190,3 +190,34 @@ def test_token_scratch_rounds(z, monkeypatch):
 def test_invalid_arguments(z):
     with pytest.raises(z.ZgpuError):
         z.deflate_batch([b"abc"], 3)
+
+
+def test_window_priming_matches_one_piece(z):
+    # chunks of one stream whose matches may reach back into the chunks before them compress
+    # like the stream in one piece; without priming every chunk starts with a cold window
+    import torch
+    import _gpu_verify as gv
+    N = z._native
+    d = zo.gen({"gen": "text", "n": 3 * 1048576 + 54321, "seed": 11})
+    (whole,), _, _ = z.deflate_batch([d], 2, 0)
+    for chunk in (65536, 262144, 1 << 20):
+        chunks = [d[i:i + chunk] for i in range(0, d.size, chunk)]
+        cold, _, _ = z.deflate_batch(chunks, 2, 0, flags=N.F_SYNC_ALIGN | N.F_FINAL_LAST)
+        warm, crc, _ = z.deflate_batch(chunks, 2, 0, flags=N.F_SYNC_ALIGN | N.F_FINAL_LAST | N.F_PRIME_WINDOW,
+                                       want_crc=True)
+        stream = b"".join(warm)
+        got, used = zo.inflate_raw(stream, d.size, want_used=True)
+        assert got == d.tobytes() and used == len(stream)
+        assert [int(c) for c in crc] == [zo.crc32(c) for c in chunks]
+        n_cold, n_warm = sum(map(len, cold)), len(stream)
+        assert n_warm < n_cold
+        assert n_warm <= 1.005 * len(whole) + 5 * len(chunks), (chunk, n_warm, n_cold, len(whole))
+        # every chunk on the device verifier, which lets matches reach into earlier chunks only when told so
+        co = np.zeros(len(warm) + 1, dtype=np.int64)
+        co[1:] = np.cumsum([len(o) for o in warm])
+        oo = np.arange(len(chunks) + 1, dtype=np.int64) * chunk
+        oo[-1] = d.size
+        args = (torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy()).cuda(), torch.from_numpy(co).cuda(),
+                torch.from_numpy(d).cuda(), torch.from_numpy(oo).cuda())
+        assert gv.verify(*args, final_each=False, primed=True).tolist() == [0] * len(chunks)
+        assert any(gv.verify(*args, final_each=False, primed=False).tolist()[1:])

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZGPU_LIB") or os.path.join(_HERE, "libzgpu.so")
 
 NONE, FIXED, DYNAMIC = 0, 1, 2
-F_FINAL_EACH, F_SYNC_ALIGN, F_FINAL_LAST, F_WANT_CRC, F_WANT_ADLER = 1, 2, 4, 16, 32
+F_FINAL_EACH, F_SYNC_ALIGN, F_FINAL_LAST, F_PRIME_WINDOW, F_WANT_CRC, F_WANT_ADLER = 1, 2, 4, 8, 16, 32
 
 # every symbol include/zgpu.h declares
 SYMBOLS = [

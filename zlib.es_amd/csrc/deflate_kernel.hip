@@ -522,6 +522,8 @@ struct Params {
     uint32_t *counter;          // unit queue head (relative to unit_first)
     uint32_t unit_first, unit_end;
     int lazy, max_chain, nice;
+    uint32_t prime;             // bytes before a unit that belong to the same stream and prime its window (0: none)
+    uint64_t stream_start;      // in_off of the stream's first byte (primed units never reach before it)
     unsigned long long *prof;   // 16 phase counters (diagnostic builds) or null
 };
 
@@ -546,8 +548,19 @@ __device__ __forceinline__ void search_units(const Params &P) {
         __syncthreads();
         if (u >= P.unit_end) break;
 
-        const uint8_t *in = P.in + P.in_off[u];
-        const uint32_t n = (uint32_t)(P.in_off[u + 1] - P.in_off[u]);
+        // A unit that continues a stream starts `pr` bytes early: those bytes (the end of the
+        // previous unit) go through the insert step only, so matches may reach back into them
+        // as a decoder of the concatenated stream can; tokens start at position pr.
+        const uint64_t uoff = P.in_off[u];
+        const uint32_t n_unit = (uint32_t)(P.in_off[u + 1] - uoff);
+        uint32_t pr = 0;
+        if (P.prime && n_unit) {
+            const uint64_t before = uoff - P.stream_start;
+            pr = (uint32_t)(before < P.prime ? before : P.prime) & ~63u;
+        }
+        const uint8_t *in = P.in + uoff - pr;
+        const uint32_t n = n_unit + pr;
+        const uint32_t prime_items = pr >> 6;
         uint32_t *tokbuf = P.tok + P.tok_off[u];  // of the block in progress
 
         // ---- unit init ----
@@ -565,7 +578,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 misc[M_ITEM] = 0;
                 misc[M_LINK] = 0;
                 misc[M_PARSE] = 0;
-                misc[M_ENTRY] = 0;
+                misc[M_ENTRY] = pr;
                 misc[M_NTOK] = 0;
                 misc[M_LOADED] = hi;
                 misc[M_LOCK] = 0;
@@ -593,8 +606,10 @@ __device__ __forceinline__ void search_units(const Params &P) {
             __syncthreads();
         };
         if (n == 0) flush_block(0);
-        for (uint32_t blk_first = 0; blk_first < nitems; blk_first += BLK_ITEMS) {
-            const uint32_t blk_end = blk_first + BLK_ITEMS < nitems ? blk_first + BLK_ITEMS : nitems;
+        // block b covers the unit's bytes [b * 64 KiB, ...): the priming items ride with block 0
+        for (uint32_t blk = 0, blk_first = 0; blk_first < nitems; ++blk) {
+            const uint32_t blk_cap = prime_items + (blk + 1) * BLK_ITEMS;
+            const uint32_t blk_end = blk_cap < nitems ? blk_cap : nitems;
             // ---- item loop: every wave takes the next 64 positions, no workgroup barrier ----
             // The parse of an item is deferred until the wave has searched its next item, so
             // that the in-order parse hand-off rarely has to wait for a slower earlier item.
@@ -782,7 +797,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 PH_END(11);
                 // ---- search ----
                 uint32_t best_len = 0, best_dist = 0;
-                {
+                if (k >= prime_items) {  // priming items are only inserted
                     const uint32_t maxlen = p < n ? ((n - p) < 258u ? (n - p) : 258u) : 0u;
                     const uint32_t limit = p < MAXDIST ? p : MAXDIST;
                     uint32_t blen = 2;
@@ -937,8 +952,9 @@ __device__ __forceinline__ void search_units(const Params &P) {
             __syncthreads();
             PH_END(1);
             if (tid == 0) misc[M_ITEM] = blk_end;  // the counter overshoots by one per wave
-            flush_block(blk_first / BLK_ITEMS);
+            flush_block(blk);
             tokbuf += ZGPU_BLOCK_TOK;
+            blk_first = blk_end;
         }
 
         PH_FLUSH();

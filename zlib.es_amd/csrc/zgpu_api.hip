@@ -151,7 +151,7 @@ struct zgpu_plan {
     uint32_t n_units = 0;
     int ctype = 2, lazy = 0;
     uint32_t flags = 0;
-    uint64_t in_total = 0, out_bound = 0, tmp_bytes = 0;
+    uint64_t in_total = 0, out_bound = 0, tmp_bytes = 0, stream_start = 0;
     uint64_t *d_in_off = nullptr, *d_slot_off = nullptr, *d_out_off = nullptr;
     uint32_t *d_out_size = nullptr, *d_status = nullptr, *d_crc = nullptr, *d_adler = nullptr;
     uint32_t *d_tok = nullptr, *d_counter = nullptr;
@@ -274,6 +274,7 @@ int zgpu_plan_create(zgpu_plan **out, const uint64_t *in_off, uint32_t n_units, 
     p->lazy = lazy;
     p->flags = flags;
     p->in_total = in_off[n_units];
+    p->stream_start = in_off[0];
     std::vector<uint64_t> slot(n_units + 1);
     uint64_t acc = 0;
     for (uint32_t i = 0; i < n_units; ++i) {
@@ -406,6 +407,8 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             P.lazy = p->lazy > g_min_lazy ? p->lazy : g_min_lazy;
             P.max_chain = g_max_chain;
             P.nice = g_nice;
+            P.prime = (p->flags & ZGPU_F_PRIME_WINDOW) && (p->flags & ZGPU_F_SYNC_ALIGN) ? 32768u : 0u;
+            P.stream_start = p->stream_start;
             P.prof = g_prof;
             const int sgrid = (int)(cnt < (uint32_t)p->ds->cus ? cnt : (uint32_t)p->ds->cus);
             if (g_nice > 32)

@@ -81,7 +81,9 @@ __constant__ uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5,
                                         9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-__device__ uint32_t verify_unit(const uint8_t *comp, uint64_t clen, const uint8_t *orig, uint64_t n, bool want_final) {
+// back: bytes of the same stream that precede orig (a chunk's matches may reach into them)
+__device__ uint32_t verify_unit(const uint8_t *comp, uint64_t clen, const uint8_t *orig, uint64_t n, bool want_final,
+                                uint64_t back) {
     Bits b{comp, comp + clen, 0, 0, false};
     uint16_t lsym[288], dsym[32];
     uint8_t lengths[320];
@@ -176,10 +178,11 @@ __device__ uint32_t verify_unit(const uint8_t *comp, uint64_t clen, const uint8_
                 if (ds >= 30) return ZGPU_V_SYMBOL;
                 const uint32_t dist = kDistBase[ds] + b.take(kDistExtra[ds]);
                 if (b.starved) return ZGPU_V_TRUNCATED;
-                if (dist > pos) return ZGPU_V_DISTANCE;
+                if (dist > pos + back) return ZGPU_V_DISTANCE;
                 if (pos + len > n) return ZGPU_V_LENGTH;
+                const uint8_t *src = orig + (int64_t)pos - (int64_t)dist;  // may lie before orig
                 for (uint32_t i = 0; i < len; ++i)
-                    if (orig[pos + i] != orig[pos + i - dist]) return ZGPU_V_MISMATCH;
+                    if (orig[pos + i] != src[i]) return ZGPU_V_MISMATCH;
                 pos += len;
             }
         }
@@ -200,8 +203,9 @@ zgpu_verify_kernel(const uint8_t *comp, const uint64_t *comp_off, const uint8_t 
     const uint32_t u = blockIdx.x * 64 + threadIdx.x;
     if (u >= n_units) return;
     const bool want_final = (flags & 1u) || u == n_units - 1;
+    const uint64_t back = (flags & 2u) ? orig_off[u] - orig_off[0] : 0;
     status[u] = verify_unit(comp + comp_off[u], comp_off[u + 1] - comp_off[u], orig + orig_off[u],
-                            orig_off[u + 1] - orig_off[u], want_final);
+                            orig_off[u + 1] - orig_off[u], want_final, back);
 }
 
 extern "C" int zgpu_verify_streams(const void *d_comp, const uint64_t *d_comp_off, const void *d_orig,
