@@ -76,6 +76,17 @@ int zgpu_last_hip_error(void);
  * and takes the one that runs longest -- about a quarter slower on highly
  * repetitive input, which then comes out up to 15 % smaller. */
 int zgpu_set_search(int max_chain, int nice_length);
+/* In a batch too small to keep every compute unit busy, a unit longer than two
+ * pieces is cut into pieces (batch bytes / 4 / compute units, at least 128 KiB,
+ * at most piece_bytes) which are compressed side by side as chunks of the
+ * unit's one stream (each ends
+ * byte-aligned with an empty stored block; its window is primed with the
+ * 32 KiB before it), so that one long input -- one RawDeflate#compress() call
+ * on a large buffer, src/rawdeflate.js:102-124 -- uses the whole GPU instead of
+ * one compute unit.  The unit's output is still one stream at one offset.
+ * Default 1 MiB; at least 1 MiB; 0 = never cut.  Results do not depend on the
+ * GPU model only when cutting is off. */
+int zgpu_set_split(uint64_t piece_bytes);
 /* The parse defers a match shorter than max(lazy, min_lazy) by one position
  * when the next position matches longer (the reference's `lazy` rule,
  * src/rawdeflate.js:339-347, applied from min_lazy even when lazy is 0).

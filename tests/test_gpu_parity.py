@@ -71,7 +71,8 @@ def test_checksum_resumable(z):
     assert z.CRC32.calc(d, 10, 1000) == zo.crc32(d[10:1010])
 
 
-def _roundtrip(z, datas, ctype, lazy=0):
+def _roundtrip(z, datas, ctype, lazy=0, joins=False):
+    # joins: pieces of a cut unit are joined by empty stored blocks (at most one per 128 KiB)
     outs, crcs, adls = z.deflate_batch(datas, ctype, lazy, want_crc=True, want_adler=True)
     sizes = []
     for d, o, c, a in zip(datas, outs, crcs, adls):
@@ -79,7 +80,9 @@ def _roundtrip(z, datas, ctype, lazy=0):
         got, used, counts = zo.inflate_raw(o, d.size, want_stats=True)
         assert got == d.tobytes()
         assert used == len(o)
-        assert counts[ctype] >= 1 and counts.sum() == counts[ctype]
+        extra = counts.sum() - counts[ctype]
+        assert counts[ctype] >= 1
+        assert extra == 0 or (joins and extra == counts[0] <= d.size >> 17)
         assert c == zo.crc32(d) and a == zo.adler32(d)
         sizes.append(len(o))
     return sizes
@@ -149,13 +152,19 @@ def test_unaligned_units_in_one_batch(z):
 
 
 def test_large_unit_sliding_window(z):
-    # a unit longer than the 64 KiB LDS ring exercises ring refill and wrap
+    # a unit longer than the 64 KiB LDS ring exercises ring refill and wrap: in one piece
+    # (cutting off), and cut into pieces as a small batch is by default
     d = zo.gen({"gen": "text", "n": 1 << 20, "seed": 42})
-    (s,) = _roundtrip(z, [d], 2)
-    ref = len(zo.rawdeflate(d, 2, heap32=True))
-    assert s <= RATIO_BAR * ref
     d2 = zo.gen({"gen": "rndseq", "n": 300_000, "seed": 9})
-    _roundtrip(z, [d2, d], 1)
+    ref = len(zo.rawdeflate(d, 2, heap32=True))
+    try:
+        for piece in (0, 1 << 20):
+            z._native.set_split(piece)
+            (s,) = _roundtrip(z, [d], 2, joins=piece > 0)
+            assert s <= RATIO_BAR * ref
+            _roundtrip(z, [d2, d], 1, joins=piece > 0)
+    finally:
+        z._native.set_split(1 << 20)
 
 
 def test_sync_align_concatenates(z):
@@ -221,3 +230,40 @@ def test_window_priming_matches_one_piece(z):
                 torch.from_numpy(d).cuda(), torch.from_numpy(oo).cuda())
         assert gv.verify(*args, final_each=False, primed=True).tolist() == [0] * len(chunks)
         assert any(gv.verify(*args, final_each=False, primed=False).tolist()[1:])
+
+
+def test_long_units_are_cut_into_pieces(z):
+    # one long input is compressed by many workgroups as chunks of its one stream; the caller
+    # still gets one stream per unit, its checksums, and a size close to the one-piece stream
+    N = z._native
+    big = zo.gen({"gen": "text", "n": 5 * 1048576 + 4321, "seed": 21})
+    mid = zo.gen({"gen": "rndseq", "n": 2 * 1048576 + 1, "seed": 22})
+    small = zo.gen({"gen": "text", "n": 70000, "seed": 23})
+    edge = zo.gen({"gen": "rnd", "n": 2 * 131072, "seed": 24})           # two minimum pieces: not cut
+    units = [small, big, np.zeros(0, dtype=np.uint8), mid, edge, small]
+    try:
+        N.set_split(0)
+        one, crc1, _ = z.deflate_batch(units, 2, 0, want_crc=True)
+        N.set_split(1 << 20)
+        for ct in (2, 1):
+            outs, crc, adl = z.deflate_batch(units, ct, 0, want_crc=True, want_adler=True)
+            for u, o, c, a in zip(units, outs, crc, adl):
+                got, used = zo.inflate_raw(o, u.size, want_used=True)
+                assert got == u.tobytes() and used == len(o)
+                assert (c, a) == (zo.crc32(u), zo.adler32(u))
+                assert len(o) <= z.deflate_bound(u.size)
+            if ct == 2:
+                assert crc == crc1
+                assert outs[0] == one[0] and outs[4] == one[4] and outs[5] == one[5]  # short units: untouched
+                assert len(outs[1]) <= 1.005 * len(one[1]) + 64
+                assert len(outs[3]) <= 1.02 * len(one[3]) + 64
+        # chunked streams made of long chunks
+        chunks = [big, mid]
+        outs, _, _ = z.deflate_batch(chunks, 2, 0, flags=N.F_SYNC_ALIGN | N.F_FINAL_LAST | N.F_PRIME_WINDOW)
+        whole = np.concatenate(chunks)
+        stream = b"".join(outs)
+        got, used = zo.inflate_raw(stream, whole.size, want_used=True)
+        assert got == whole.tobytes() and used == len(stream)
+        assert outs[0][-4:] == b"\x00\x00\xff\xff"
+    finally:
+        N.set_split(1 << 20)

@@ -17,7 +17,7 @@ F_FINAL_EACH, F_SYNC_ALIGN, F_FINAL_LAST, F_PRIME_WINDOW, F_WANT_CRC, F_WANT_ADL
 
 # every symbol include/zgpu.h declares
 SYMBOLS = [
-    "zgpu_init", "zgpu_shutdown", "zgpu_strerror", "zgpu_last_hip_error", "zgpu_set_search",
+    "zgpu_init", "zgpu_shutdown", "zgpu_strerror", "zgpu_last_hip_error", "zgpu_set_search", "zgpu_set_split",
     "zgpu_set_min_lazy",
     "zgpu_deflate_bound", "zgpu_deflate_batch", "zgpu_plan_create", "zgpu_plan_destroy",
     "zgpu_plan_out_bound", "zgpu_plan_run", "zgpu_plan_out_off_device", "zgpu_plan_crc_device",
@@ -55,6 +55,8 @@ def lib():
     L.zgpu_last_hip_error.restype = i32
     L.zgpu_set_search.restype = i32
     L.zgpu_set_search.argtypes = [i32, i32]
+    L.zgpu_set_split.restype = i32
+    L.zgpu_set_split.argtypes = [C.c_uint64]
     L.zgpu_set_min_lazy.restype = i32
     L.zgpu_set_min_lazy.argtypes = [i32]
     L.zgpu_deflate_bound.restype = u64
@@ -113,6 +115,10 @@ def deflate_bound(n):
 
 def set_search(max_chain, nice_length=32):
     _check(lib().zgpu_set_search(max_chain, nice_length), "zgpu_set_search")
+
+
+def set_split(piece_bytes):
+    _check(lib().zgpu_set_split(piece_bytes), "zgpu_set_split")
 
 
 def set_min_lazy(min_lazy):

@@ -522,8 +522,7 @@ struct Params {
     uint32_t *counter;          // unit queue head (relative to unit_first)
     uint32_t unit_first, unit_end;
     int lazy, max_chain, nice;
-    uint32_t prime;             // bytes before a unit that belong to the same stream and prime its window (0: none)
-    uint64_t stream_start;      // in_off of the stream's first byte (primed units never reach before it)
+    const uint32_t *unit_prime; // per unit: bytes before it (same stream, multiple of 64, <= 32 KiB) that prime its window
     unsigned long long *prof;   // 16 phase counters (diagnostic builds) or null
 };
 
@@ -553,11 +552,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
         // as a decoder of the concatenated stream can; tokens start at position pr.
         const uint64_t uoff = P.in_off[u];
         const uint32_t n_unit = (uint32_t)(P.in_off[u + 1] - uoff);
-        uint32_t pr = 0;
-        if (P.prime && n_unit) {
-            const uint64_t before = uoff - P.stream_start;
-            pr = (uint32_t)(before < P.prime ? before : P.prime) & ~63u;
-        }
+        const uint32_t pr = n_unit ? P.unit_prime[u] : 0u;
         const uint8_t *in = P.in + uoff - pr;
         const uint32_t n = n_unit + pr;
         const uint32_t prime_items = pr >> 6;
@@ -991,9 +986,9 @@ struct EParams {
     const uint32_t *hist;      // blocks x 320 symbol counts (lit/len 288, dist 32)
     const uint32_t *ntok;      // blocks: tokens incl. end-of-block
     uint32_t *counter;         // unit queue head (relative to unit_first)
-    uint32_t unit_first, unit_end, n_units;
+    const uint8_t *unit_final; // n_units: 1 = the unit ends its stream (BFINAL), 0 = it ends with an empty stored block
+    uint32_t unit_first, unit_end;
     int ctype;
-    uint32_t flags;
 };
 
 }  // namespace
@@ -1014,8 +1009,7 @@ zgpu_emit_kernel(EParams P) {
         const uint32_t n = (uint32_t)(P.in_off[u + 1] - P.in_off[u]);
         uint32_t *out32 = (uint32_t *)(P.out_tmp + P.slot_off[u]);
         const uint32_t cap_words = (uint32_t)((P.slot_off[u + 1] - P.slot_off[u]) >> 2);
-        const bool final_unit =
-            (P.flags & 1u) || ((P.flags & 4u) && u == P.n_units - 1) || !(P.flags & 2u);
+        const bool final_unit = P.unit_final[u] != 0;
         const uint32_t nblk = n ? (n + ZGPU_BLOCK_BYTES - 1) / ZGPU_BLOCK_BYTES : 1u;
         uint32_t bitpos = 0;     // bits emitted so far in this unit (uniform)
         uint32_t base_word = 0;  // output word index of stage[0] (uniform)
@@ -1516,4 +1510,12 @@ zgpu_compact_kernel(const uint8_t *out_tmp, const uint64_t *slot_off, const uint
         }
         for (uint64_t i = headb + body + threadIdx.x; i < len; i += blockDim.x) dst[i] = src[i];
     }
+}
+
+// ---- per-unit output offsets when long units were cut into pieces -------------
+extern "C" __global__ void __launch_bounds__(256)
+zgpu_unit_offsets_kernel(const uint64_t *piece_out_off, const uint32_t *first_piece, uint64_t *unit_out_off,
+                         uint32_t n_units) {
+    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
+    if (u <= n_units) unit_out_off[u] = piece_out_off[first_piece[u]];
 }

@@ -20,6 +20,7 @@ namespace {
 thread_local int g_last_hip = 0;
 int g_max_chain = 8;
 int g_nice = 32;
+uint64_t g_split_bytes = 1ull << 20;  // units longer than twice this are cut into pieces of at most this size
 int g_min_lazy = 258;  // the parse always looks one position ahead unless told otherwise
 unsigned long long *g_prof = nullptr;  // diagnostic builds only
 
@@ -151,7 +152,14 @@ struct zgpu_plan {
     uint32_t n_units = 0;
     int ctype = 2, lazy = 0;
     uint32_t flags = 0;
-    uint64_t in_total = 0, out_bound = 0, tmp_bytes = 0, stream_start = 0;
+    uint64_t in_total = 0, out_bound = 0, tmp_bytes = 0;
+    uint32_t n_pieces = 0;           // what the kernels see: units, the long ones cut into pieces
+    bool split = false;              // some unit has more than one piece
+    uint32_t *d_prime = nullptr;     // per piece: bytes before it that prime its window
+    uint8_t *d_final = nullptr;      // per piece: ends its stream
+    uint64_t *d_unit_in_off = nullptr, *d_unit_out_off = nullptr;  // per unit (only when split)
+    uint32_t *d_first_piece = nullptr;
+    std::vector<uint32_t> first_piece;
     uint64_t *d_in_off = nullptr, *d_slot_off = nullptr, *d_out_off = nullptr;
     uint32_t *d_out_size = nullptr, *d_status = nullptr, *d_crc = nullptr, *d_adler = nullptr;
     uint32_t *d_tok = nullptr, *d_counter = nullptr;
@@ -245,6 +253,12 @@ int zgpu_set_search(int max_chain, int nice_length) {
     return ZGPU_OK;
 }
 
+int zgpu_set_split(uint64_t piece_bytes) {
+    if (piece_bytes && piece_bytes < (1ull << 20)) return ZGPU_E_ARG;
+    g_split_bytes = piece_bytes;
+    return ZGPU_OK;
+}
+
 int zgpu_set_min_lazy(int min_lazy) {
     if (min_lazy < 0 || min_lazy > 258) return ZGPU_E_ARG;
     g_min_lazy = min_lazy;
@@ -252,7 +266,8 @@ int zgpu_set_min_lazy(int min_lazy) {
 }
 
 uint64_t zgpu_deflate_bound(uint64_t in_len) {
-    return in_len + in_len / 8 + (in_len / 65536 + 1) * 400 + 64;
+    // worst-case literal codes, per-block headers, and for long units the framing of their pieces
+    return in_len + in_len / 8 + (in_len / 65536 + 1) * 400 + 64 + (in_len >> 17) * 512;
 }
 
 int zgpu_plan_create(zgpu_plan **out, const uint64_t *in_off, uint32_t n_units, int ctype, int lazy,
@@ -274,21 +289,61 @@ int zgpu_plan_create(zgpu_plan **out, const uint64_t *in_off, uint32_t n_units, 
     p->lazy = lazy;
     p->flags = flags;
     p->in_total = in_off[n_units];
-    p->stream_start = in_off[0];
-    std::vector<uint64_t> slot(n_units + 1);
-    uint64_t acc = 0;
-    for (uint32_t i = 0; i < n_units; ++i) {
-        slot[i] = acc;
-        acc += align_up(zgpu_deflate_bound(in_off[i + 1] - in_off[i]) + 32, 16);
+    // ---- pieces: what the kernels work on.  A unit longer than twice the split size is cut
+    // into pieces of that size, each compressed by its own workgroup as a chunk of the unit's
+    // stream: byte-aligned end (empty stored block), window primed with the 32 KiB before it.
+    // A unit's pieces are consecutive, so its output is their concatenation.
+    const bool chunked = (flags & ZGPU_F_SYNC_ALIGN) && !(flags & ZGPU_F_FINAL_EACH);
+    const bool prime_units = chunked && (flags & ZGPU_F_PRIME_WINDOW);
+    // Piece size: a batch with fewer units than keep the CUs busy four times over cuts units longer
+    // than two pieces into pieces of total / (4 x CUs) bytes, between 128 KiB and the set limit.
+    uint64_t piece = 0;
+    if (ctype != ZGPU_NONE && g_split_bytes && n_units < 4u * (uint32_t)ds->cus) {
+        piece = align_up((in_off[n_units] - in_off[0]) / (4ull * (uint64_t)ds->cus) + 1, 65536);
+        if (piece < (128u << 10)) piece = 128u << 10;
+        if (piece > g_split_bytes) piece = g_split_bytes;
     }
-    slot[n_units] = acc;
+    std::vector<uint64_t> pc_off;        // piece offsets into the input, n_pieces + 1
+    std::vector<uint32_t> first_piece;   // per unit, n_units + 1
+    std::vector<uint32_t> pc_prime;      // bytes of the same stream before the piece that prime its window
+    std::vector<uint8_t> pc_final;       // piece ends its stream (BFINAL) / ends with an empty stored block
+    for (uint32_t i = 0; i < n_units; ++i) {
+        const uint64_t o = in_off[i], n = in_off[i + 1] - o;
+        const uint64_t split = (piece && n > 2 * piece) ? piece : 0;
+        const uint64_t np = split ? (n + split - 1) / split : 1;
+        const bool unit_final = !chunked || ((flags & ZGPU_F_FINAL_LAST) && i == n_units - 1);
+        first_piece.push_back((uint32_t)pc_off.size());
+        for (uint64_t k = 0; k < np; ++k) {
+            pc_off.push_back(o + k * split);
+            uint64_t before = k ? k * split : (prime_units ? o - in_off[0] : 0);
+            if (before > 32768) before = 32768;
+            pc_prime.push_back((uint32_t)before & ~63u);
+            pc_final.push_back(unit_final && k == np - 1);
+        }
+        if (pc_off.size() > 0x7fffffffull) {
+            delete p;
+            return ZGPU_E_TOOBIG;
+        }
+    }
+    const uint32_t n_pieces = (uint32_t)pc_off.size();
+    first_piece.push_back(n_pieces);
+    pc_off.push_back(in_off[n_units]);
+    p->n_pieces = n_pieces;
+    p->split = n_pieces != n_units;
+    std::vector<uint64_t> slot(n_pieces + 1);
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < n_pieces; ++i) {
+        slot[i] = acc;
+        acc += align_up(zgpu_deflate_bound(pc_off[i + 1] - pc_off[i]) + 32, 16);
+    }
+    slot[n_pieces] = acc;
     p->tmp_bytes = acc;
     p->out_bound = acc;
-    // Token scratch: 4 bytes per input byte in the worst case.  Units are cut into rounds
+    // Token scratch: 4 bytes per input byte in the worst case.  Pieces are cut into rounds
     // whose tokens fit a buffer of at most a third of the free device memory (ZGPU_TOK_BYTES
-    // overrides; never less than one maximum-size unit needs).
-    std::vector<uint64_t> tok_off(n_units);
-    std::vector<uint32_t> blk_first(n_units);
+    // overrides; never less than one maximum-size piece needs).
+    std::vector<uint64_t> tok_off(n_pieces);
+    std::vector<uint32_t> blk_first(n_pieces);
     uint64_t tok_buf_tokens = 0, n_blocks = 0;
     if (ctype != ZGPU_NONE) {
         size_t free_b = 0, total_b = 0;
@@ -298,8 +353,8 @@ int zgpu_plan_create(zgpu_plan **out, const uint64_t *in_off, uint32_t n_units, 
         const uint64_t cap_tokens = cap_bytes / 4;
         uint64_t used = 0;
         uint32_t first = 0;
-        for (uint32_t i = 0; i < n_units; ++i) {
-            const uint64_t n = in_off[i + 1] - in_off[i], need = unit_tok_cap(n);
+        for (uint32_t i = 0; i < n_pieces; ++i) {
+            const uint64_t n = pc_off[i + 1] - pc_off[i], need = unit_tok_cap(n);
             if (used && used + need > cap_tokens) {
                 p->rounds.push_back({first, i});
                 first = i;
@@ -315,7 +370,7 @@ int zgpu_plan_create(zgpu_plan **out, const uint64_t *in_off, uint32_t n_units, 
             blk_first[i] = (uint32_t)n_blocks;
             n_blocks += unit_blocks(n);
         }
-        p->rounds.push_back({first, n_units});
+        p->rounds.push_back({first, n_pieces});
     }
 #define PCHK(expr)                 \
     do {                           \
@@ -326,27 +381,40 @@ int zgpu_plan_create(zgpu_plan **out, const uint64_t *in_off, uint32_t n_units, 
             return e_ == hipErrorOutOfMemory ? ZGPU_E_NOMEM : ZGPU_E_NODEVICE; \
         }                          \
     } while (0)
-    const size_t offb = (size_t)(n_units + 1) * 8;
+    const size_t offb = (size_t)(n_pieces + 1) * 8, uoffb = (size_t)(n_units + 1) * 8;
     PCHK(hipMalloc(&p->d_in_off, offb));
     PCHK(hipMalloc(&p->d_slot_off, offb));
     PCHK(hipMalloc(&p->d_out_off, offb));
-    PCHK(hipMalloc(&p->d_out_size, (size_t)n_units * 4));
-    PCHK(hipMalloc(&p->d_status, (size_t)n_units * 4));
+    PCHK(hipMalloc(&p->d_out_size, (size_t)n_pieces * 4));
+    PCHK(hipMalloc(&p->d_status, (size_t)n_pieces * 4));
+    PCHK(hipMalloc(&p->d_prime, (size_t)n_pieces * 4));
+    PCHK(hipMalloc(&p->d_final, (size_t)n_pieces));
     PCHK(hipMalloc(&p->d_crc, (size_t)n_units * 4));
     PCHK(hipMalloc(&p->d_adler, (size_t)n_units * 4));
     PCHK(hipMalloc(&p->d_counter, (p->rounds.size() * 2 + 2) * 4));
     PCHK(hipMalloc(&p->d_out_tmp, p->tmp_bytes + 64));
     if (ctype != ZGPU_NONE) {
         PCHK(hipMalloc(&p->d_tok, (size_t)tok_buf_tokens * 4 + 64));
-        PCHK(hipMalloc(&p->d_tok_off, (size_t)n_units * 8));
-        PCHK(hipMalloc(&p->d_blk_first, (size_t)n_units * 4));
+        PCHK(hipMalloc(&p->d_tok_off, (size_t)n_pieces * 8));
+        PCHK(hipMalloc(&p->d_blk_first, (size_t)n_pieces * 4));
         PCHK(hipMalloc(&p->d_hist, (size_t)n_blocks * 320 * 4));
         PCHK(hipMalloc(&p->d_ntok, (size_t)n_blocks * 4));
-        PCHK(hipMemcpy(p->d_tok_off, tok_off.data(), (size_t)n_units * 8, hipMemcpyHostToDevice));
-        PCHK(hipMemcpy(p->d_blk_first, blk_first.data(), (size_t)n_units * 4, hipMemcpyHostToDevice));
+        PCHK(hipMemcpy(p->d_tok_off, tok_off.data(), (size_t)n_pieces * 8, hipMemcpyHostToDevice));
+        PCHK(hipMemcpy(p->d_blk_first, blk_first.data(), (size_t)n_pieces * 4, hipMemcpyHostToDevice));
     }
-    PCHK(hipMemcpy(p->d_in_off, in_off, offb, hipMemcpyHostToDevice));
+    PCHK(hipMemcpy(p->d_in_off, pc_off.data(), offb, hipMemcpyHostToDevice));
     PCHK(hipMemcpy(p->d_slot_off, slot.data(), offb, hipMemcpyHostToDevice));
+    PCHK(hipMemcpy(p->d_prime, pc_prime.data(), (size_t)n_pieces * 4, hipMemcpyHostToDevice));
+    PCHK(hipMemcpy(p->d_final, pc_final.data(), (size_t)n_pieces, hipMemcpyHostToDevice));
+    if (p->split) {
+        // the caller's view: unit offsets into the input, first piece of every unit, output offsets
+        PCHK(hipMalloc(&p->d_unit_in_off, uoffb));
+        PCHK(hipMalloc(&p->d_first_piece, (size_t)(n_units + 1) * 4));
+        PCHK(hipMalloc(&p->d_unit_out_off, uoffb));
+        PCHK(hipMemcpy(p->d_unit_in_off, in_off, uoffb, hipMemcpyHostToDevice));
+        PCHK(hipMemcpy(p->d_first_piece, first_piece.data(), (size_t)(n_units + 1) * 4, hipMemcpyHostToDevice));
+        p->first_piece = first_piece;
+    }
     PCHK(hipMemset(p->d_crc, 0, (size_t)n_units * 4));
     PCHK(hipMemset(p->d_adler, 0, (size_t)n_units * 4));
     for (int i = 0; i < 5; ++i) PCHK(hipEventCreate(&p->ev[i]));
@@ -371,6 +439,11 @@ void zgpu_plan_destroy(zgpu_plan *p) {
     (void)hipFree(p->d_blk_first);
     (void)hipFree(p->d_hist);
     (void)hipFree(p->d_ntok);
+    (void)hipFree(p->d_prime);
+    (void)hipFree(p->d_final);
+    (void)hipFree(p->d_unit_in_off);
+    (void)hipFree(p->d_unit_out_off);
+    (void)hipFree(p->d_first_piece);
     for (int i = 0; i < 5; ++i)
         if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
     delete p;
@@ -407,8 +480,7 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             P.lazy = p->lazy > g_min_lazy ? p->lazy : g_min_lazy;
             P.max_chain = g_max_chain;
             P.nice = g_nice;
-            P.prime = (p->flags & ZGPU_F_PRIME_WINDOW) && (p->flags & ZGPU_F_SYNC_ALIGN) ? 32768u : 0u;
-            P.stream_start = p->stream_start;
+            P.unit_prime = p->d_prime;
             P.prof = g_prof;
             const int sgrid = (int)(cnt < (uint32_t)p->ds->cus ? cnt : (uint32_t)p->ds->cus);
             if (g_nice > 32)
@@ -430,9 +502,8 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             E.counter = p->d_counter + 2 * r + 1;
             E.unit_first = first;
             E.unit_end = end;
-            E.n_units = p->n_units;
+            E.unit_final = p->d_final;
             E.ctype = p->ctype;
-            E.flags = p->flags;
             const uint32_t emax = (uint32_t)p->ds->cus * ZGPU_EMIT_WG_PER_CU;
             hipLaunchKernelGGL(zgpu_emit_kernel, dim3(cnt < emax ? cnt : emax), dim3(256), 0, st, E);
         }
@@ -440,18 +511,21 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(p->ev[2], st));
     hipLaunchKernelGGL(zgpu_scan_kernel, dim3(1), dim3(1024), 0, st, p->d_out_size, p->d_out_off,
-                       p->n_units);
+                       p->n_pieces);
     {
-        int grid = p->n_units < (uint32_t)p->ds->cus * 8 ? (int)p->n_units : p->ds->cus * 8;
+        int grid = p->n_pieces < (uint32_t)p->ds->cus * 8 ? (int)p->n_pieces : p->ds->cus * 8;
         hipLaunchKernelGGL(zgpu_compact_kernel, dim3(grid), dim3(256), 0, st, p->d_out_tmp,
                            p->d_slot_off, p->d_out_off, (uint8_t *)d_out, out_cap, p->d_status,
-                           p->n_units);
+                           p->n_pieces);
     }
+    if (p->split)
+        hipLaunchKernelGGL(zgpu_unit_offsets_kernel, dim3(p->n_units / 256 + 1), dim3(256), 0, st, p->d_out_off,
+                           p->d_first_piece, p->d_unit_out_off, p->n_units);
     if (p->flags & (ZGPU_F_WANT_CRC | ZGPU_F_WANT_ADLER)) {
         int grid = p->n_units < (uint32_t)p->ds->cus * 8 ? (int)p->n_units : p->ds->cus * 8;
         hipLaunchKernelGGL(zgpu_checksum_kernel, dim3(grid), dim3(ZGPU_CK_THREADS), 0, st,
-                           (const uint8_t *)d_in, p->d_in_off, p->n_units, p->ds->d_tables, p->d_crc,
-                           p->d_adler);
+                           (const uint8_t *)d_in, p->split ? p->d_unit_in_off : p->d_in_off, p->n_units,
+                           p->ds->d_tables, p->d_crc, p->d_adler);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(p->ev[3], st));
@@ -459,7 +533,9 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
     return ZGPU_OK;
 }
 
-const uint64_t *zgpu_plan_out_off_device(const zgpu_plan *p) { return p ? p->d_out_off : nullptr; }
+const uint64_t *zgpu_plan_out_off_device(const zgpu_plan *p) {
+    return p ? (p->split ? p->d_unit_out_off : p->d_out_off) : nullptr;
+}
 const uint32_t *zgpu_plan_crc_device(const zgpu_plan *p) { return p ? p->d_crc : nullptr; }
 const uint32_t *zgpu_plan_adler_device(const zgpu_plan *p) { return p ? p->d_adler : nullptr; }
 
@@ -467,14 +543,15 @@ int zgpu_plan_fetch(zgpu_plan *p, uint64_t *out_off, uint32_t *crc32, uint32_t *
     if (!p || !p->ran) return ZGPU_E_ARG;
     hipStream_t st = (hipStream_t)stream_;
     HIPCHK(hipStreamSynchronize(st));
-    std::vector<uint32_t> status(p->n_units);
-    HIPCHK(hipMemcpy(status.data(), p->d_status, (size_t)p->n_units * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> status(p->n_pieces);
+    HIPCHK(hipMemcpy(status.data(), p->d_status, (size_t)p->n_pieces * 4, hipMemcpyDeviceToHost));
     if (out_off)
-        HIPCHK(hipMemcpy(out_off, p->d_out_off, (size_t)(p->n_units + 1) * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out_off, p->split ? p->d_unit_out_off : p->d_out_off, (size_t)(p->n_units + 1) * 8,
+                         hipMemcpyDeviceToHost));
     if (crc32) HIPCHK(hipMemcpy(crc32, p->d_crc, (size_t)p->n_units * 4, hipMemcpyDeviceToHost));
     if (adler32) HIPCHK(hipMemcpy(adler32, p->d_adler, (size_t)p->n_units * 4, hipMemcpyDeviceToHost));
     int rc = ZGPU_OK;
-    for (uint32_t i = 0; i < p->n_units; ++i) {
+    for (uint32_t i = 0; i < p->n_pieces; ++i) {
         if (status[i] == 2) rc = ZGPU_E_OUTCAP;
         else if (status[i] && rc == ZGPU_OK) rc = ZGPU_E_UNIT;
     }
