@@ -166,7 +166,7 @@ it('Zip: many small files in one batch', () => {
 });
 
 // ---- chunked single-member streams (sync-aligned chunks + checksum combine) ----
-it('gzipChunked: one member, many independently compressed chunks', () => {
+it('gzipChunked: one member, many chunks compressed side by side', () => {
 	const data = H.makeText(3 * 1048576 + 12345, 7);
 	const gz = gzipChunked(data, { chunkSize: 1 << 20, mtime: 0 });
 	assert.ok(H.equal(nodeZlib.gunzipSync(Buffer.from(gz)), data)); // checks CRC-32 and ISIZE
@@ -174,6 +174,12 @@ it('gzipChunked: one member, many independently compressed chunks', () => {
 	assert.strictEqual(d.crc32, H.crc32(data));
 	assert.strictEqual(d.adler32, H.adler32(data));
 	assert.ok(H.equal(nodeZlib.inflateRawSync(Buffer.concat(d.parts.map((p) => Buffer.from(p)))), data));
+	// independent chunks: every chunk but the last decodes alone once given a final empty block
+	const ind = deflateChunked(data, { chunkSize: 65536, independent: true });
+	const alone = Buffer.concat([Buffer.from(ind.parts[1]), Buffer.from([1, 0, 0, 0xff, 0xff])]);
+	assert.ok(H.equal(nodeZlib.inflateRawSync(alone), data.subarray(65536, 131072)));
+	const size = (r) => r.parts.reduce((s, p) => s + p.length, 0);
+	assert.ok(size(d) <= size(ind));
 });
 
 // ---- batch API ----

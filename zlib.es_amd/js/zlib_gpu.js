@@ -15,7 +15,7 @@ const path = require('path');
 const addon = require('./zgpu_addon.node');
 addon.init(path.join(__dirname, '..', 'libzgpu.so'));
 
-const F_FINAL_EACH = 1, F_SYNC_ALIGN = 2, F_FINAL_LAST = 4;
+const F_FINAL_EACH = 1, F_SYNC_ALIGN = 2, F_FINAL_LAST = 4, F_PRIME_WINDOW = 8;
 
 function asU8(input) {
 	if (input instanceof Uint8Array) return input;
@@ -441,9 +441,11 @@ Zip.FileHeaderSignature = [0x50, 0x4b, 0x01, 0x02];
 Zip.LocalFileHeaderSignature = [0x50, 0x4b, 0x03, 0x04];
 Zip.CentralDirectorySignature = [0x50, 0x4b, 0x05, 0x06];
 
-// chunked single-member gzip / zlib bodies: the input is cut into independent
-// chunks, each ends byte-aligned (empty stored block), the last carries BFINAL;
-// whole-stream CRC-32 / Adler-32 come from the per-chunk values by combine.
+// chunked single-member gzip / zlib bodies: the input is cut into chunks
+// compressed side by side, each ends byte-aligned (empty stored block), the last
+// carries BFINAL; whole-stream CRC-32 / Adler-32 come from the per-chunk values by
+// combine.  A chunk may match into the 32 KiB before it unless opt.independent is
+// set (then every chunk decodes without its predecessors, at a slightly larger size).
 function deflateChunked(input, opt) {
 	const o = opt || {};
 	const a = asU8(input);
@@ -454,7 +456,8 @@ function deflateChunked(input, opt) {
 		parts.push(a.subarray(p, Math.min(a.length, p + chunk)));
 		if (a.length === 0) break;
 	}
-	const r = addon.deflateBatch(parts, ct, o.lazy | 0, F_SYNC_ALIGN | F_FINAL_LAST, true, true);
+	const flags = F_SYNC_ALIGN | F_FINAL_LAST | (o.independent ? 0 : F_PRIME_WINDOW);
+	const r = addon.deflateBatch(parts, ct, o.lazy | 0, flags, true, true);
 	let crc = r.crc32[0], adler = r.adler32[0];
 	for (let i = 1; i < parts.length; ++i) {
 		crc = addon.crc32Combine(crc, r.crc32[i], parts[i].length);

@@ -71,14 +71,18 @@ def compress_sharded(units, ctype=N.DYNAMIC, lazy=0, flags=N.F_FINAL_EACH, compr
     return outs, crcs, adlers
 
 
-def gzip_chunked(data, chunk_size=1 << 20, ctype=N.DYNAMIC, lazy=0, mtime=0, compress_fn=None):
-    """One gzip member whose body is made of independently compressed chunks
+def gzip_chunked(data, chunk_size=1 << 20, ctype=N.DYNAMIC, lazy=0, mtime=0, compress_fn=None,
+                 independent=False):
+    """One gzip member whose body is made of chunks compressed side by side
     (each byte-aligned by an empty stored block, BFINAL on the last), with the
-    CRC-32 trailer obtained by combine.  Container framing as src/gzip.js:67-83,
-    :117-126.  Returns bytes on rank 0 (None on other ranks)."""
+    CRC-32 trailer obtained by combine.  A chunk may match into the 32 KiB before
+    it (the first chunk of a rank's range has none) unless `independent`.
+    Container framing as src/gzip.js:67-83, :117-126.  Returns bytes on rank 0
+    (None on other ranks)."""
     a = N._u8(data)
     chunks = [a[i:i + chunk_size] for i in range(0, a.size, chunk_size)] or [a]
-    res = compress_sharded(chunks, ctype, lazy, N.F_SYNC_ALIGN | N.F_FINAL_LAST, compress_fn)
+    flags = N.F_SYNC_ALIGN | N.F_FINAL_LAST | (0 if independent else N.F_PRIME_WINDOW)
+    res = compress_sharded(chunks, ctype, lazy, flags, compress_fn)
     if res is None:
         return None
     outs, crcs, adlers = res
