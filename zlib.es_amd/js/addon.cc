@@ -33,6 +33,7 @@ struct Lib {
     fn_strerror strerror_ = nullptr;
     fn_set2 set_search = nullptr;
     fn_set1 set_min_lazy = nullptr;
+    int (*set_split)(uint64_t) = nullptr;
 } g;
 
 #define NAPI_OK(call)                                            \
@@ -78,8 +79,9 @@ napi_value Init_(napi_env env, napi_callback_info info) {
     g.strerror_ = (fn_strerror)dlsym(h, "zgpu_strerror");
     g.set_search = (fn_set2)dlsym(h, "zgpu_set_search");
     g.set_min_lazy = (fn_set1)dlsym(h, "zgpu_set_min_lazy");
+    g.set_split = (int (*)(uint64_t))dlsym(h, "zgpu_set_split");
     if (!g.deflate_batch || !g.checksum || !g.bound || !g.crc_combine || !g.adler_combine || !g.strerror_ ||
-        !g.set_search || !g.set_min_lazy) {
+        !g.set_search || !g.set_min_lazy || !g.set_split) {
         dlclose(h);
         napi_throw_error(env, nullptr, "libzgpu.so lacks an expected symbol");
         return nullptr;
@@ -236,7 +238,7 @@ napi_value SetSearch(napi_env env, napi_callback_info info) {
     size_t argc = 2;
     napi_value argv[2];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
-    int32_t a = 0, b = 258;
+    int32_t a = 0, b = 32;
     NAPI_OK(napi_get_value_int32(env, argv[0], &a));
     if (argc > 1) NAPI_OK(napi_get_value_int32(env, argv[1], &b));
     int rc = g.set_search(a, b);
@@ -256,6 +258,19 @@ napi_value SetMinLazy(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 
+napi_value SetSplit(napi_env env, napi_callback_info info) {
+    if (!need_lib(env)) return nullptr;
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    double a = 0;
+    NAPI_OK(napi_get_value_double(env, argv[0], &a));
+    if (!(a >= 0 && a <= 9007199254740992.0)) return throw_zgpu(env, "zgpu_set_split", -2);
+    int rc = g.set_split((uint64_t)a);
+    if (rc) return throw_zgpu(env, "zgpu_set_split", rc);
+    return nullptr;
+}
+
 napi_value ModuleInit(napi_env env, napi_value exports) {
     const napi_property_descriptor props[] = {
         {"init", nullptr, Init_, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
@@ -266,6 +281,7 @@ napi_value ModuleInit(napi_env env, napi_value exports) {
         {"deflateBound", nullptr, DeflateBound, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setSearch", nullptr, SetSearch, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setMinLazy", nullptr, SetMinLazy, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setSplit", nullptr, SetSplit, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     };
     if (napi_define_properties(env, exports, sizeof props / sizeof props[0], props) != napi_ok) return nullptr;
     return exports;
