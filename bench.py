@@ -134,8 +134,8 @@ def main():
 
     import zlib_es_amd as z
     N = z._native
-    if args.chain:
-        z.set_search(args.chain, args.nice)
+    if args.chain or args.nice != 32:
+        z.set_search(args.chain or 8, args.nice)
 
     def barrier():
         torch.cuda.synchronize()

@@ -114,6 +114,21 @@ def test_ratio_vs_reference(z, golden, ctype):
     assert tot_gpu <= RATIO_BAR * tot_ref, (tot_gpu, tot_ref)
 
 
+@pytest.mark.parametrize("ctype", [1, 2])
+def test_exhaustive_search_meets_the_bar_case_by_case(z, golden, ctype):
+    # chain budget as long as the window + nice_length 258 = the reference's exhaustive search
+    # (src/rawdeflate.js:370-395): every named case, not only their sum, is within the bar
+    cases = [c for c in golden["cases"] if c["n"] >= 16384]
+    datas = [zo.gen(c["spec"]) for c in cases]
+    z.set_search(32768, 258)
+    try:
+        sizes = _roundtrip(z, datas, ctype)
+    finally:
+        z.set_search(8, 32)
+    for c, s in zip(cases, sizes):
+        assert s <= RATIO_BAR * c["raw"][str(ctype)]["len"], (c["spec"], s)
+
+
 def test_roundtrip_edge_sizes(z):
     rng = np.random.default_rng(11)
     datas = []

@@ -526,8 +526,11 @@ struct Params {
     unsigned long long *prof;   // 16 phase counters (diagnostic builds) or null
 };
 
-// THOROUGH: the chain walk goes on past candidates that reach the compare cap and
-// pass 2 settles which of them runs longest (chosen by nice_length > CMP_CAP).
+// THOROUGH (chosen by nice_length > CMP_CAP): a candidate that reaches the compare
+// cap is compared to its full length on the spot and the walk goes on until a
+// candidate is nice_length long or the chain budget ends -- with nice_length 258 and
+// a budget as long as the window that is the reference's exhaustive search
+// (src/rawdeflate.js:370-395: longest wins, the nearest among equals).
 template <bool THOROUGH>
 __device__ __forceinline__ void search_units(const Params &P) {
     __shared__ __align__(16) uint8_t lds_raw[L_TOTAL];
@@ -796,14 +799,14 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     const uint32_t maxlen = p < n ? ((n - p) < 258u ? (n - p) : 258u) : 0u;
                     const uint32_t limit = p < MAXDIST ? p : MAXDIST;
                     uint32_t blen = 2;
-                    uint32_t ex0 = 0, ex1 = 0, ex2 = 0;  // further candidates that reached the compare cap
                     {
                         // pass 1, lane per position: walk the hash chain.  A candidate costs one
-                        // LDS round trip: its chain link and its first 16 bytes (one unaligned
-                        // 128-bit read) are fetched together and compared against this position's
-                        // 16 bytes held in registers, so there is no per-lane compare loop for the
-                        // wave to diverge on.  Only a candidate that matches all 16 bytes reads 16
-                        // more (CMP_CAP; pass 2 finds the exact length of long matches).
+                        // LDS round trip: its chain link and its first 16 bytes (aligned dword
+                        // reads, see ld16) are fetched together and compared against this
+                        // position's 16 bytes held in registers, so there is no per-lane compare
+                        // loop for the wave to diverge on.  Only a candidate that matches all 16
+                        // bytes reads 16 more (CMP_CAP; pass 2 finds the exact length of long
+                        // matches).
                         const uint32_t pi = p & (RING - 1);
                         const uint32_t cmpmax = maxlen < CMP_CAP ? maxlen : CMP_CAP;
                         if (p + 3 <= n) {
@@ -818,25 +821,26 @@ __device__ __forceinline__ void search_units(const Params &P) {
                                 uint32_t len = mlen16(own, ld16(ring, ci));
                                 if (len == 16 && cmpmax > 16)
                                     len = 16 + mlen16(ld16(ring, pi + 16), ld16(ring, ci + 16));
-                                if (len > cmpmax) len = cmpmax;
+                                if (THOROUGH) {
+                                    if (len == CMP_CAP) {
+                                        while (len < maxlen) {
+                                            const uint32_t m = mlen16(ld16(ring, (pi + len) & (RING - 1)),
+                                                                      ld16(ring, (ci + len) & (RING - 1)));
+                                            len += m;
+                                            if (m < 16) break;
+                                        }
+                                    }
+                                    if (len > maxlen) len = maxlen;
+                                } else if (len > cmpmax) {
+                                    len = cmpmax;
+                                }
                                 if (len > blen) {
                                     blen = len;
                                     best_dist = dist;
                                     // as long as the unit allows, or as long as the caller finds nice
                                     // (nice <= CMP_CAP, the default: the first capped candidate ends
-                                    // the walk; beyond it the walk goes on and collects the others)
+                                    // the walk and pass 2 finds its exact length)
                                     if (len >= maxlen || len >= (uint32_t)P.nice) break;
-                                } else if (THOROUGH && len == CMP_CAP) {
-                                    // another candidate that reached the compare cap: which of them
-                                    // runs longest is settled in pass 2
-                                    if (!ex0)
-                                        ex0 = dist;
-                                    else if (!ex1)
-                                        ex1 = dist;
-                                    else {
-                                        ex2 = dist;
-                                        break;
-                                    }
                                 }
                                 c = nxt;
                             }
@@ -849,28 +853,13 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         // compare per lane, a ballot, and count-trailing-ones give every lane
                         // its exact match length (up to 258) at that distance.
                         // Offers: every lane's best distance if it is long enough to be worth
-                        // sharing, and the other candidates that reached the compare cap.
+                        // sharing.
                         const uint32_t offer = best_dist;
                         constexpr int share_iters = THOROUGH ? SHARE_ITERS_THOROUGH : SHARE_ITERS;
                         unsigned long long todo = __ballot(blen >= SHARE_MIN);
-                        unsigned long long todo0 = 0, todo1 = 0, todo2 = 0;
-                        if (THOROUGH) {
-                            todo0 = __ballot(ex0 != 0);
-                            todo1 = __ballot(ex1 != 0);
-                            todo2 = __ballot(ex2 != 0);
-                        }
                         for (int it = 0; it < share_iters; ++it) {
-                            uint32_t d;
-                            if (todo)
-                                d = (uint32_t)__shfl((int)offer, __builtin_ctzll(todo), 64);
-                            else if (THOROUGH && todo0)
-                                d = (uint32_t)__shfl((int)ex0, __builtin_ctzll(todo0), 64);
-                            else if (THOROUGH && todo1)
-                                d = (uint32_t)__shfl((int)ex1, __builtin_ctzll(todo1), 64);
-                            else if (THOROUGH && todo2)
-                                d = (uint32_t)__shfl((int)ex2, __builtin_ctzll(todo2), 64);
-                            else
-                                break;
+                            if (!todo) break;
+                            const uint32_t d = (uint32_t)__shfl((int)offer, __builtin_ctzll(todo), 64);
                             uint32_t run = 0;
                             bool open = true;
                             for (uint32_t w = 0; w < 6; ++w) {
@@ -896,11 +885,6 @@ __device__ __forceinline__ void search_units(const Params &P) {
                                 best_dist = d;
                             }
                             todo &= ~__ballot(offer == d);
-                            if (THOROUGH) {
-                                todo0 &= ~__ballot(ex0 == d);
-                                todo1 &= ~__ballot(ex1 == d);
-                                todo2 &= ~__ballot(ex2 == d);
-                            }
                         }
                     }
                     if (blen >= 3 && !(blen == 3 && best_dist > 4096)) best_len = blen;

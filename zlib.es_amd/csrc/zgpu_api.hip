@@ -247,7 +247,7 @@ int zgpu_prof_read(unsigned long long *out8, int reset) {
 #endif
 
 int zgpu_set_search(int max_chain, int nice_length) {
-    if (max_chain < 1 || max_chain > 4096 || nice_length < 3 || nice_length > 258) return ZGPU_E_ARG;
+    if (max_chain < 1 || max_chain > 32768 || nice_length < 3 || nice_length > 258) return ZGPU_E_ARG;
     g_max_chain = max_chain;
     g_nice = nice_length;
     return ZGPU_OK;
