@@ -61,8 +61,11 @@ enum {
 #define ZGPU_MAX_UNIT_BYTES (256u << 20)
 
 /* ---- library state ------------------------------------------------------ */
-/* Selects the devices the host-buffer entry points may use (NULL/0 = the
- * current device).  Optional: every entry point initialises lazily. */
+/* Names the devices the host-buffer entry points may use (NULL/0 = whichever
+ * device is current): a call made while another device is current runs on the
+ * first one named and restores the caller's device.  Optional: every entry
+ * point initialises lazily.  Device-pointer entry points (zgpu_plan_*,
+ * zgpu_checksum_device) always use the current device. */
 int zgpu_init(const int *device_ids, int n_devices);
 void zgpu_shutdown(void);
 const char *zgpu_strerror(int code);

@@ -158,6 +158,27 @@ def test_lazy_roundtrip_and_gain(z):
     assert s8 <= s0 and s32 <= s8 * 1.001
 
 
+def test_host_batch_with_nonzero_first_offset(z):
+    # the units are a slice in the middle of a larger host buffer: offsets are absolute
+    N = z._native
+    big = zo.gen({"gen": "text", "n": 3_000_000, "seed": 77})
+    for base in (1_000_003, 1 << 20):
+        cuts = np.array([0, 70_000, 70_001, 200_000, 200_000, 333_333], dtype=np.uint64) + np.uint64(base)
+        n = cuts.size - 1
+        cap = sum(N.deflate_bound(int(b - a)) + 48 for a, b in zip(cuts, cuts[1:])) + 64
+        out = np.empty(cap, dtype=np.uint8)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        crc = np.zeros(n, dtype=np.uint32)
+        rc = N.lib().zgpu_deflate_batch(big.ctypes.data, cuts.ctypes.data, n, 2, 0, N.F_FINAL_EACH, out.ctypes.data,
+                                        cap, out_off.ctypes.data, crc.ctypes.data, None)
+        assert rc == 0
+        for i in range(n):
+            d = big[int(cuts[i]):int(cuts[i + 1])]
+            o = out[int(out_off[i]):int(out_off[i + 1])].tobytes()
+            assert zo.inflate_raw(o, d.size) == d.tobytes()
+            assert int(crc[i]) == zo.crc32(d)
+
+
 def test_unaligned_units_in_one_batch(z):
     # zip-like packing: units start at arbitrary byte offsets inside one buffer
     rng = np.random.default_rng(2)

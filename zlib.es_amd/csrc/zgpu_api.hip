@@ -67,6 +67,7 @@ struct DeviceState {
     uint64_t seg_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ck_ms = 0.f;
+    std::mutex ck_mu;  // zgpu_checksum_device calls on one device share the scratch above
 };
 std::mutex g_mu;
 std::vector<DeviceState *> g_devs;
@@ -113,6 +114,51 @@ void build_tables_wide(const std::vector<uint32_t> &t, std::vector<uint32_t> &w)
     for (int i = 0; i < 256; ++i) w[15 * 2048 + 10 + i] = t[i];
 }
 
+void free_state(DeviceState *s) {
+    (void)hipFree(s->d_tables);
+    (void)hipFree(s->d_tables_wide);
+    (void)hipFree(s->d_seg_off);
+    (void)hipFree(s->d_seg_crc);
+    (void)hipFree(s->d_seg_adler);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    delete s;
+}
+
+// The host-buffer entry points run on the current device, or, when zgpu_init named
+// devices and the current one is not among them, on the first named; the caller's
+// current device is restored on return.
+struct HostDeviceScope {
+    int prev = -1;
+    int rc = ZGPU_OK;
+    HostDeviceScope() {
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) {
+            rc = ZGPU_E_NODEVICE;
+            return;
+        }
+        int want = cur;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            if (!g_allowed.empty()) {
+                want = g_allowed[0];
+                for (int d : g_allowed)
+                    if (d == cur) want = cur;
+            }
+        }
+        if (want != cur) {
+            if (hipSetDevice(want) != hipSuccess) {
+                rc = ZGPU_E_NODEVICE;
+                return;
+            }
+            prev = cur;
+        }
+    }
+    ~HostDeviceScope() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 int get_state(DeviceState **out) {
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
@@ -125,19 +171,26 @@ int get_state(DeviceState **out) {
     auto *s = new (std::nothrow) DeviceState();
     if (!s) return ZGPU_E_NOMEM;
     s->device = dev;
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, dev));
-    s->cus = prop.multiProcessorCount;
-    std::vector<uint32_t> t;
-    build_tables(t);
-    HIPCHK(hipMalloc(&s->d_tables, t.size() * 4));
-    HIPCHK(hipMemcpy(s->d_tables, t.data(), t.size() * 4, hipMemcpyHostToDevice));
-    std::vector<uint32_t> tw;
-    build_tables_wide(t, tw);
-    HIPCHK(hipMalloc(&s->d_tables_wide, tw.size() * 4));
-    HIPCHK(hipMemcpy(s->d_tables_wide, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipEventCreate(&s->ev0));
-    HIPCHK(hipEventCreate(&s->ev1));
+    const int rc = [&]() -> int {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, dev));
+        s->cus = prop.multiProcessorCount;
+        std::vector<uint32_t> t;
+        build_tables(t);
+        HIPCHK(hipMalloc(&s->d_tables, t.size() * 4));
+        HIPCHK(hipMemcpy(s->d_tables, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+        std::vector<uint32_t> tw;
+        build_tables_wide(t, tw);
+        HIPCHK(hipMalloc(&s->d_tables_wide, tw.size() * 4));
+        HIPCHK(hipMemcpy(s->d_tables_wide, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipEventCreate(&s->ev0));
+        HIPCHK(hipEventCreate(&s->ev1));
+        return ZGPU_OK;
+    }();
+    if (rc) {
+        free_state(s);
+        return rc;
+    }
     g_devs.push_back(s);
     *out = s;
     return ZGPU_OK;
@@ -203,14 +256,7 @@ void zgpu_shutdown(void) {
     (void)hipGetDevice(&cur);
     for (auto *s : g_devs) {
         (void)hipSetDevice(s->device);
-        (void)hipFree(s->d_tables);
-        (void)hipFree(s->d_tables_wide);
-        (void)hipFree(s->d_seg_off);
-        (void)hipFree(s->d_seg_crc);
-        (void)hipFree(s->d_seg_adler);
-        if (s->ev0) (void)hipEventDestroy(s->ev0);
-        if (s->ev1) (void)hipEventDestroy(s->ev1);
-        delete s;
+        free_state(s);
     }
     g_devs.clear();
     (void)hipSetDevice(cur);
@@ -581,6 +627,8 @@ int zgpu_deflate_batch(const uint8_t *in, const uint64_t *in_off, uint32_t n_uni
                        uint32_t flags, uint8_t *out, uint64_t out_cap, uint64_t *out_off,
                        uint32_t *crc32, uint32_t *adler32) {
     if (!in_off || !out || !out_off) return ZGPU_E_ARG;
+    HostDeviceScope scope;
+    if (scope.rc) return scope.rc;
     if (crc32) flags |= ZGPU_F_WANT_CRC;
     if (adler32) flags |= ZGPU_F_WANT_ADLER;
     zgpu_plan *p = nullptr;
@@ -595,14 +643,18 @@ int zgpu_deflate_batch(const uint8_t *in, const uint64_t *in_off, uint32_t n_uni
         return code;
     };
     hipError_t e;
-    // the plan indexes d_in with the caller's absolute offsets
-    if ((e = hipMalloc(&d_in, in_off[n_units] + 64)) != hipSuccess) { g_last_hip = e; return fail(ZGPU_E_NOMEM); }
+    // The plan indexes its input with the caller's absolute offsets: only the bytes of the
+    // units are allocated and copied, and the base pointer handed to the plan is moved back by
+    // the first offset (kept congruent modulo 256 so the kernels see the caller's alignment).
+    const uint64_t lead = base & 255u;
+    if ((e = hipMalloc(&d_in, lead + total + 64)) != hipSuccess) { g_last_hip = e; return fail(ZGPU_E_NOMEM); }
     if ((e = hipMalloc(&d_out, p->out_bound + 64)) != hipSuccess) { g_last_hip = e; return fail(ZGPU_E_NOMEM); }
-    if (total && (e = hipMemcpy(d_in + base, in + base, total, hipMemcpyHostToDevice)) != hipSuccess) {
+    if (total && (e = hipMemcpy(d_in + lead, in + base, total, hipMemcpyHostToDevice)) != hipSuccess) {
         g_last_hip = e;
         return fail(ZGPU_E_NODEVICE);
     }
-    rc = zgpu_plan_run(p, d_in, d_out, p->out_bound, nullptr);
+    const uint8_t *d_in0 = (const uint8_t *)((uintptr_t)d_in + lead - base);
+    rc = zgpu_plan_run(p, d_in0, d_out, p->out_bound, nullptr);
     if (rc) return fail(rc);
     rc = zgpu_plan_fetch(p, out_off, crc32, adler32, nullptr);
     if (rc) return fail(rc);
@@ -635,6 +687,7 @@ int zgpu_checksum_device(const void *d_in, uint64_t len, uint32_t *crc32, uint32
     DeviceState *ds = nullptr;
     int rc = get_state(&ds);
     if (rc) return rc;
+    std::lock_guard<std::mutex> ck_lock(ds->ck_mu);
     hipStream_t st = (hipStream_t)stream_;
     // large buffers go through the wide kernel (one workgroup per CU, 4 MiB segments)
     const bool wide = len >= ZGPU_CKW_MIN_BYTES;
@@ -696,6 +749,8 @@ int zgpu_checksum_kernel_ms(float *ms) {
 
 int zgpu_checksum(const uint8_t *in, uint64_t len, uint32_t *crc32, uint32_t *adler32) {
     if (!in && len) return ZGPU_E_ARG;
+    HostDeviceScope scope;
+    if (scope.rc) return scope.rc;
     uint8_t *d = nullptr;
     HIPCHK(hipMalloc(&d, len + 64));
     hipError_t e = len ? hipMemcpy(d, in, len, hipMemcpyHostToDevice) : hipSuccess;
