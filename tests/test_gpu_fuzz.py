@@ -4,6 +4,8 @@ oracle: unit sizes from 0 to a few blocks, all content kinds, both Huffman
 modes, lazy settings, independent streams and chunked streams, several search
 depths.  The encoder's waves hand work to each other through LDS flags; a
 batch of a few thousand units of uneven sizes is what shakes that out."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -33,7 +35,11 @@ def _unit(rng, i):
     return zo.gen(spec)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+# ZGPU_FUZZ_SEEDS="a-b" widens the run (default: three seeds, about ten seconds)
+_lo, _hi = (int(x) for x in os.environ.get("ZGPU_FUZZ_SEEDS", "1-3").split("-"))
+
+
+@pytest.mark.parametrize("seed", list(range(_lo, _hi + 1)))
 def test_random_batches(seed):
     import zlib_es_amd as z
     N = z._native
@@ -48,16 +54,21 @@ def test_random_batches(seed):
     crc_ref = [zo.crc32(d) for d in datas[:50]]
     adl_ref = [zo.adler32(d) for d in datas[:50]]
     try:
-        for ctype, lazy, chain, nice, chunked in [(2, 0, 8, 32, False), (1, 0, 8, 258, False), (2, 16, 3, 32, False),
-                                                  (2, 0, 32, 258, True), (1, 7, 1, 8, True)]:
+        # chunked: 1 = units are chunks of one stream, 2 = and each may match into the 32 KiB before it
+        for ctype, lazy, chain, nice, chunked in [(2, 0, 8, 32, 0), (1, 0, 8, 258, 0), (2, 16, 3, 32, 0),
+                                                  (2, 0, 32, 258, 1), (1, 7, 1, 8, 1), (2, 0, 8, 32, 2),
+                                                  (1, 3, 5, 40, 2)]:
             z.set_search(chain, nice)
             flags = (N.F_SYNC_ALIGN | N.F_FINAL_LAST) if chunked else N.F_FINAL_EACH
+            if chunked == 2:
+                flags |= N.F_PRIME_WINDOW
             outs, crc, adl = z.deflate_batch(datas, ctype, lazy, flags=flags, want_crc=True, want_adler=True)
             assert crc[:50] == crc_ref and adl[:50] == adl_ref
             co = np.zeros(len(outs) + 1, dtype=np.int64)
             co[1:] = np.cumsum([len(o) for o in outs])
             d_comp = torch.from_numpy(np.frombuffer(b"".join(outs), dtype=np.uint8).copy()).cuda()
-            st = gv.verify(d_comp, torch.from_numpy(co).cuda(), d_orig, d_ooff, final_each=not chunked)
+            st = gv.verify(d_comp, torch.from_numpy(co).cuda(), d_orig, d_ooff, final_each=not chunked,
+                           primed=chunked == 2)
             bad = [(i, gv.STATUS[int(s)], datas[i].size) for i, s in enumerate(st.tolist()) if s]
             assert not bad, (ctype, lazy, chain, nice, chunked, bad[:5])
             if chunked:

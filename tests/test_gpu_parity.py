@@ -129,6 +129,41 @@ def test_exhaustive_search_meets_the_bar_case_by_case(z, golden, ctype):
         assert s <= RATIO_BAR * c["raw"][str(ctype)]["len"], (c["spec"], s)
 
 
+def _planted(rng, n, tail):
+    """Random bytes with planted repeats: the k-th largest entry of `tail` is how many matches of
+    the k-th base length of RFC 1951 (3, 4, ..., 10, 11, 13, ...) the data holds, each a copy
+    from at most 3000 bytes back that neither starts earlier nor runs longer."""
+    base = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227]
+    d = rng.integers(0, 256, n, dtype=np.uint8)
+    jobs = [ln for ln, cnt in zip(base, sorted(tail, reverse=True)) for _ in range(cnt)]
+    rng.shuffle(jobs)
+    cur = 4000
+    for ln in jobs:
+        src = cur - int(rng.integers(ln + 10, 3000))
+        d[cur:cur + ln] = d[src:src + ln]
+        if d[cur - 1] == d[src - 1]:
+            d[cur - 1] ^= 0x55
+        if d[cur + ln] == d[src + ln]:
+            d[cur + ln] ^= 0x55
+        cur += ln + int(rng.integers(8, 20))
+        assert cur + 300 < n
+    return d
+
+
+def test_skewed_histograms_hit_the_code_length_limit(z):
+    # 256 literals of about equal weight put the literals 8 levels down; length symbols whose
+    # counts grow like a Fibonacci sequence then form a chain that reaches level 17 or 18, past
+    # the 15-bit limit.  The repair has to free exactly the over-subscribed amount, which depends
+    # on how deep the clamped leaves were and not only on how many there are.
+    rng = np.random.default_rng(7)
+    tails = ([1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233], [2, 2, 4, 6, 10, 16, 26, 42, 68, 110, 178],
+             [2, 2, 4, 6, 10, 16, 26, 42, 68, 110, 178, 240], [1] * 9 + [2, 3, 3, 5, 5, 5, 8, 8, 10, 10, 13, 15, 15, 15, 16, 21])
+    datas = [_planted(rng, 65536, t) for t in tails]
+    datas.append(np.concatenate([_planted(rng, 65536, tails[0]), _planted(rng, 40000, tails[1][:9])]))
+    for lazy in (0, 4):
+        _roundtrip(z, datas, 2, lazy)
+
+
 def test_roundtrip_edge_sizes(z):
     rng = np.random.default_rng(11)
     datas = []

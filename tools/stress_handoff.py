@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Stress of the search kernel's wave-to-wave hand-offs: batches of units of uneven sizes are
+compressed over and over with search settings that make the search itself short (so the
+waves spend their time in the linking and parsing hand-offs), and every output stream is
+checked on the device each time.
+
+usage: stress_handoff.py [REPS] [UNITS]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench  # noqa: E402
+import _gpu_verify as gv  # noqa: E402
+import zlib_es_amd as z  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+nu = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+dev = torch.device("cuda:0")
+torch.cuda.init()
+data = bench.gen_units(nu, 65536, 5, dev)
+rng = np.random.default_rng(3)
+# uneven unit sizes over the same bytes: 1 B .. 400 KB
+cuts = [0]
+total = nu * 65536
+while cuts[-1] < total:
+    r = rng.random()
+    n = int(rng.integers(1, 3000)) if r < 0.2 else int(rng.integers(3000, 140000)) if r < 0.9 else int(rng.integers(140000, 400000))
+    cuts.append(min(total, cuts[-1] + n))
+in_off = np.array(cuts, dtype=np.uint64)
+d_in_off = torch.from_numpy(in_off.astype(np.int64)).to(dev)
+bad_total = 0
+t0 = time.time()
+for rep in range(reps):
+    chain, nice, ctype = [(1, 8, 1), (1, 3, 2), (2, 32, 2), (8, 32, 2)][rep % 4]
+    z.set_search(chain, nice)
+    plan = z.Plan(in_off, ctype, 0, z._native.F_FINAL_EACH)
+    out = torch.empty(plan.out_bound + 64, dtype=torch.uint8, device=dev)
+    plan.run(data.data_ptr(), out.data_ptr(), out.numel(), None)
+    off, _, _ = plan.fetch()
+    st = gv.verify(out, torch.from_numpy(off.astype(np.int64)).to(dev), data, d_in_off, True)
+    bad = (st != 0).nonzero().flatten().tolist()
+    bad_total += len(bad)
+    if bad or rep % 10 == 0:
+        print("rep %d chain %d nice %d ctype %d: %d units, bad %s (%.0f s)" % (
+            rep, chain, nice, ctype, in_off.size - 1, [(u, int(in_off[u + 1] - in_off[u])) for u in bad[:5]],
+            time.time() - t0), flush=True)
+    del plan, out
+z.set_search(8, 32)
+print("failures:", bad_total)
+sys.exit(1 if bad_total else 0)

@@ -68,9 +68,12 @@ constexpr uint32_t NSLOT = 64;                       // > LAG
 constexpr uint32_t S_EXIT = 0;                       // u16[NSLOT*64]
 constexpr uint32_t S_CNT = S_EXIT + NSLOT * 64 * 2;  // u8[NSLOT*64]
 constexpr uint32_t S_DONE = S_CNT + NSLOT * 64;      // u32[NSLOT]
-constexpr uint32_t S_ENT = S_DONE + NSLOT * 4;       // u32[NSLOT]
-constexpr uint32_t S_TOKB = S_ENT + NSLOT * 4;       // u32[NSLOT]
-constexpr uint32_t SCR_BYTES = S_TOKB + NSLOT * 4;
+// Entry position and token base of an item wait for the item's owner in a longer ring; the
+// frontier stays less than NSLOT_E items ahead of every item whose tokens are not out yet.
+constexpr uint32_t NSLOT_E = 128;
+constexpr uint32_t S_ENT = S_DONE + NSLOT * 4;       // u32[NSLOT_E]
+constexpr uint32_t S_TOKB = S_ENT + NSLOT_E * 4;     // u32[NSLOT_E]
+constexpr uint32_t SCR_BYTES = S_TOKB + NSLOT_E * 4;
 constexpr uint32_t L_TOTAL = L_SCR + SCR_BYTES;
 static_assert(L_TOTAL <= 163840, "LDS budget");
 
@@ -103,7 +106,9 @@ enum { M_SCAN = 0 /*[16]*/, M_UNIT = 32, M_NTOK = 34, M_TMP = 35, M_OVF = 36,
        M_PARSE = 42,   // item whose turn it is to take the parse hand-off
        M_ENTRY = 43,   // unit position of the next token (belongs to item M_PARSE)
        M_LOADED = 44,  // input bytes resident in the ring (exclusive end)
-       M_LOCK = 45     // try-lock of the parse frontier
+       M_LOCK = 45,    // try-lock of the parse frontier
+       M_SAFE = 46,    // the frontier may pass items below this without looking at M_OLDEST
+       M_OLDEST = 16   // [16] per wave: its oldest item whose tokens are not out yet (search kernel)
 };
 
 struct Lds {
@@ -452,15 +457,18 @@ __device__ void wave_huffman(const HufS &S, uint32_t m_in, uint32_t nsym, uint32
         overflow += (uint32_t)__builtin_popcountll(__ballot(over));
     }
     if (overflow && lane == 0) {
-        // move the deepest leaves up until the code fits
-        int ov = (int)overflow;
-        while (ov > 0) {
+        // Clamping leaves the code over-subscribed by some number of codes of the maximum
+        // length (how many depends on how deep the clamped leaves were, not only on their
+        // count).  One step -- the deepest leaf above the limit moves one level down and a
+        // leaf from the limit becomes its sibling -- frees exactly one such code.
+        uint32_t kraft = 0;
+        for (uint32_t b = 1; b <= maxbits; ++b) kraft += S.blc[b] << (maxbits - b);
+        for (uint32_t excess = kraft - (1u << maxbits); excess > 0; --excess) {
             uint32_t bits = maxbits - 1;
             while (S.blc[bits] == 0) --bits;
             S.blc[bits]--;
             S.blc[bits + 1] += 2;
             S.blc[maxbits]--;
-            ov -= 2;
         }
     }
     asm volatile("" ::: "memory");
@@ -580,7 +588,9 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 misc[M_NTOK] = 0;
                 misc[M_LOADED] = hi;
                 misc[M_LOCK] = 0;
+                misc[M_SAFE] = NSLOT_E;
             }
+            if (tid < WG / 64) misc[M_OLDEST + tid] = 0;
             // stamps of the previous unit's items must not be taken for this unit's
             if (tid < (int)NSLOT) ((uint32_t *)(scr + S_DONE))[tid] = 0;
         }
@@ -616,21 +626,44 @@ __device__ __forceinline__ void search_units(const Params &P) {
             // index and the number of tokens when the parse enters the item there, the
             // "searched" stamp, and -- once the parse frontier has passed the item -- its
             // entry position and token base.  Any wave moves the frontier (M_PARSE, M_ENTRY,
-            // M_NTOK) under a try-lock; it never waits for the item's owner.
+            // M_NTOK) under a try-lock; it never waits for the item's owner to search.
+            // The owner reads entry and token base when it emits the item's tokens, which can be
+            // a while after the frontier passed, so the frontier must not lap their ring before
+            // that: every wave keeps the number of its oldest item whose tokens are not out in
+            // M_OLDEST (it only grows), and the frontier stops NSLOT_E short of the smallest of
+            // them.  It looks at the 16 words only when it reaches the bound it computed the
+            // last time (M_SAFE), i.e. about once in NSLOT_E - 2 * LAG items.
             uint16_t *exit_tab = (uint16_t *)(scr + S_EXIT);
             uint8_t *cnt_tab = scr + S_CNT;
             uint32_t *slot_done = (uint32_t *)(scr + S_DONE);
             uint32_t *slot_entry = (uint32_t *)(scr + S_ENT);
             uint32_t *slot_tokb = (uint32_t *)(scr + S_TOKB);
+            auto safe_bound = [&]() -> uint32_t {
+                uint32_t o[WG / 64];
+#pragma unroll
+                for (int w = 0; w < WG / 64; ++w) o[w] = lds_ld(&misc[M_OLDEST + w]);
+                uint32_t m = o[0];
+#pragma unroll
+                for (int w = 1; w < WG / 64; ++w) m = o[w] < m ? o[w] : m;
+                return m + NSLOT_E;
+            };
             auto try_advance = [&]() {
                 if (lane == 0) {
                     for (;;) {
                         if (atomicCAS(&misc[M_LOCK], 0u, 1u) != 0u) break;  // someone else is at it
-                        uint32_t f = misc[M_PARSE], e = misc[M_ENTRY], t = misc[M_NTOK];
+                        uint32_t f = misc[M_PARSE], e = misc[M_ENTRY], t = misc[M_NTOK], safe = misc[M_SAFE];
+                        bool held = false;  // stopped by the bound, not by an unsearched item
                         while (lds_ld(&slot_done[f & (NSLOT - 1)]) == f + 1) {
+                            if (f == safe) {
+                                safe = safe_bound();
+                                if (f == safe) {
+                                    held = true;
+                                    break;
+                                }
+                            }
                             const uint32_t sl = f & (NSLOT - 1), le = e - (f << 6);
-                            slot_entry[sl] = e;
-                            slot_tokb[sl] = t;
+                            slot_entry[f & (NSLOT_E - 1)] = e;
+                            slot_tokb[f & (NSLOT_E - 1)] = t;
                             if (le < 64u) {
                                 e = (f << 6) + exit_tab[sl * 64 + le];
                                 t += cnt_tab[sl * 64 + le];
@@ -639,12 +672,16 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         }
                         misc[M_ENTRY] = e;
                         misc[M_NTOK] = t;
+                        misc[M_SAFE] = safe;
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         lds_st(&misc[M_PARSE], f);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         lds_st(&misc[M_LOCK], 0u);
-                        // an item stamped while the lock was held must not be left behind
+                        // an item stamped while the lock was held must not be left behind; nor a
+                        // bound that moved (a wave that moves it after this look finds M_PARSE
+                        // at the bound and advances the frontier itself)
                         if (lds_ld(&slot_done[f & (NSLOT - 1)]) != f + 1) break;
+                        if (held && safe_bound() == f) break;
                     }
                 }
             };
@@ -672,14 +709,15 @@ __device__ __forceinline__ void search_units(const Params &P) {
             auto resolved = [&](uint32_t k0) -> bool {
                 return (int32_t)(lds_ld(&misc[M_PARSE]) - k0) > 0;
             };
-            auto emit_oldest = [&]() {
+            // cur: the item the wave is working on (the block's end when it has taken its last)
+            auto emit_oldest = [&](uint32_t cur) {
                 // ---- tokens of item q_k[0]: lane l <-> local index l ----
                 // The parse path through the item is walked on scalar registers: literal runs
                 // are skipped with a find-first-set over the ballot of match positions, a
                 // match costs one readlane of its successor.  The path mask then gives every
                 // lane its place in the token stream by bit counts; no shuffles.
                 const uint32_t k0 = q_k[0], ld = q_ld[0];
-                const uint32_t p0 = k0 << 6, sl = k0 & (NSLOT - 1);
+                const uint32_t p0 = k0 << 6, sl = k0 & (NSLOT_E - 1);
                 const uint32_t seg_end = (n - p0) < 64u ? (n - p0) : 64u;
                 PH_START();
                 while (!resolved(k0)) {
@@ -691,6 +729,11 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 // local index of the first token (>= seg_end: a match from before covers the item)
                 const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_entry[sl]) - p0;
                 const uint32_t tokbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_tokb[sl]);
+                // both are in registers: this wave's oldest item with tokens to come is the next
+                // one.  A frontier held at this item's bound either shows in M_PARSE now, or
+                // its wave has yet to publish M_PARSE and looks at the bound again after that.
+                lds_publish(&misc[M_OLDEST + (tid >> 6)], npend > 1 ? q_k[1] : cur);
+                const bool frontier_held = lds_ld(&misc[M_PARSE]) == k0 + NSLOT_E;
                 uint32_t ldn = __shfl_down(ld, 1, 64);  // the next position's match (lazy tokens)
                 if (lane == 63) ldn = 0;
                 uint32_t kind;
@@ -739,6 +782,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 }
                 --npend;
                 PH_END(7);
+                if (frontier_held) try_advance();
             };
             for (;;) {
                 uint32_t k = 0;
@@ -746,11 +790,16 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
                 if (k >= blk_end) break;
                 PH_START();
+                if (npend == 0) {
+                    // nothing older waits in this wave (its first item of the block)
+                    lds_publish(&misc[M_OLDEST + (tid >> 6)], k);
+                    try_advance();
+                }
                 const uint32_t p0 = k << 6;
                 const uint32_t p = p0 + (uint32_t)lane;
                 // An unparsed item more than LAG items back must be parsed first, or the
                 // waves that wait for it below could never be released.
-                while (npend > 0 && k > q_k[0] + LAG) emit_oldest();
+                while (npend > 0 && k > q_k[0] + LAG) emit_oldest(k);
                 // bound the spread of in-flight items: everything more than LAG items back is
                 // parsed, so no wave still reads ring bytes or chain slots that get recycled
                 if (k > LAG) lds_wait_ge(&misc[M_PARSE], k - LAG);
@@ -915,7 +964,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 PH_END(14);
                 // tokens of items the frontier has passed leave before this item is stamped:
                 // until then the frontier cannot run far enough to recycle their slots
-                while (npend > 0 && (npend == PEND || resolved(q_k[0]))) emit_oldest();
+                while (npend > 0 && (npend == PEND || resolved(q_k[0]))) emit_oldest(k);
 #pragma unroll
                 for (int i = 0; i < PEND; ++i)
                     if (i == npend) {
@@ -926,7 +975,10 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 lds_publish(&slot_done[k & (NSLOT - 1)], k + 1);
                 try_advance();
             }
-            while (npend > 0) emit_oldest();
+            while (npend > 0) emit_oldest(blk_end);
+            // also a wave that got no item in this block must not hold the frontier back
+            lds_publish(&misc[M_OLDEST + (tid >> 6)], blk_end);
+            try_advance();
             PH_START();
             __syncthreads();
             PH_END(1);
