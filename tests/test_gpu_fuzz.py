@@ -77,3 +77,69 @@ def test_random_batches(seed):
             assert all(len(o) <= z.deflate_bound(len(d)) for o, d in zip(outs, origs))
     finally:
         z.set_search(8, 32)
+
+
+def _skewed_unit(rng):
+    """A unit whose symbol statistics are geometric: literal values, match lengths and match
+    distances each follow counts that grow by a random factor, so the three Huffman trees of a
+    block (and the code-length tree of its header) come out anywhere from flat to chains far
+    deeper than their length limits."""
+    n = int(rng.integers(2000, 66000))
+    nsym = int(rng.integers(2, 257))
+    r = float(rng.uniform(1.05, 2.3))
+    w = np.minimum(r ** np.arange(nsym), 1e6)
+    w = np.maximum(1, (w * (n / w.sum())).astype(np.int64))
+    vals = rng.permutation(256)[:nsym].astype(np.uint8)
+    d = np.repeat(vals, w)
+    rng.shuffle(d)
+    d = d[:n].copy()
+    n = d.size
+    # planted copies: lengths and distances from geometric class counts
+    lens = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+    dists = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073,
+             4097, 6145, 8193, 12289, 16385, 24577]
+    rl, rd = float(rng.uniform(1.0, 2.2)), float(rng.uniform(1.0, 2.2))
+    pl = rl ** rng.permutation(len(lens))
+    pd = rd ** rng.permutation(len(dists))
+    pl, pd = pl / pl.sum(), pd / pd.sum()
+    cur = 1
+    budget = int(rng.integers(0, 400))
+    while budget > 0 and cur + 300 < n:
+        ln = lens[int(rng.choice(len(lens), p=pl))]
+        di = dists[int(rng.choice(len(dists), p=pd))]
+        cur += int(rng.integers(1, 40))
+        if di <= cur and cur + ln < n:
+            for k in range(ln):  # byte by byte: a copy may overlap itself
+                d[cur + k] = d[cur + k - di]
+            cur += ln
+        budget -= 1
+    return d
+
+
+_slo, _shi = (int(x) for x in os.environ.get("ZGPU_FUZZ_SKEW_SEEDS", "11-12").split("-"))
+
+
+@pytest.mark.parametrize("seed", list(range(_slo, _shi + 1)))
+def test_skewed_symbol_statistics(seed):
+    import zlib_es_amd as z
+    rng = np.random.default_rng(seed)
+    datas = [_skewed_unit(rng) for _ in range(400)]
+    flat = np.concatenate(datas)
+    off = np.zeros(len(datas) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([d.size for d in datas])
+    d_orig = torch.from_numpy(flat).cuda()
+    d_ooff = torch.from_numpy(off).cuda()
+    try:
+        for chain, nice, lazy in ((8, 32, 0), (64, 258, 0), (4, 32, 8)):
+            z.set_search(chain, nice)
+            outs, _, _ = z.deflate_batch(datas, 2, lazy)
+            co = np.zeros(len(outs) + 1, dtype=np.int64)
+            co[1:] = np.cumsum([len(o) for o in outs])
+            d_comp = torch.from_numpy(np.frombuffer(b"".join(outs), dtype=np.uint8).copy()).cuda()
+            st = gv.verify(d_comp, torch.from_numpy(co).cuda(), d_orig, d_ooff)
+            bad = [(i, gv.STATUS[int(s)], datas[i].size) for i, s in enumerate(st.tolist()) if s]
+            assert not bad, (chain, nice, lazy, bad[:5])
+            for i in range(0, len(outs), 40):  # and a sample through the CPU decoder
+                assert zo.inflate_raw(outs[i], datas[i].size) == datas[i].tobytes()
+    finally:
+        z.set_search(8, 32)
