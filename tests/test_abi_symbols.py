@@ -52,3 +52,23 @@ def test_no_cpu_fallback_without_gpu():
         z.checksum(b"abc")
     with pytest.raises(z.ZgpuError):
         z.deflate_batch([b"abc"])
+
+
+def test_argument_errors_need_no_gpu():
+    # argument checks come before any device work: same codes with or without a GPU
+    import numpy as np
+    import zlib_es_amd as z
+    N = z._native
+    L = N.lib()
+    plan = ctypes.c_void_p(None)
+    too_big = np.array([0, (256 << 20) + 1], dtype=np.uint64)
+    assert L.zgpu_plan_create(ctypes.byref(plan), too_big.ctypes.data, 1, 2, 0, 1) == -6      # ZGPU_E_TOOBIG
+    ok = np.array([0, 10], dtype=np.uint64)
+    assert L.zgpu_plan_create(ctypes.byref(plan), ok.ctypes.data, 1, 3, 0, 1) == -2           # invalid compression type
+    assert L.zgpu_plan_create(ctypes.byref(plan), ok.ctypes.data, 0, 2, 0, 1) == -2           # no units
+    back = np.array([10, 0], dtype=np.uint64)
+    assert L.zgpu_plan_create(ctypes.byref(plan), back.ctypes.data, 1, 2, 0, 1) == -2         # offsets go backwards
+    assert L.zgpu_set_search(0, 32) == -2 and L.zgpu_set_search(8, 259) == -2 and L.zgpu_set_search(8, 32) == 0
+    assert L.zgpu_set_split(4096) == -2 and L.zgpu_set_split(1 << 20) == 0
+    assert L.zgpu_set_min_lazy(-1) == -2 and L.zgpu_set_min_lazy(258) == 0
+    assert b"compression type" in ctypes.cast(L.zgpu_strerror(-2), ctypes.c_char_p).value

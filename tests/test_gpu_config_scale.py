@@ -88,3 +88,40 @@ def test_config5_gzip_chunked_member(z):
     ref = sum(len(zo.rawdeflate(p, 2, heap32=True)) for p in parts[:4])
     ours, _, _ = z.deflate_batch(parts[:4], 2, 0)
     assert sum(len(o) for o in ours) <= 1.03 * ref
+
+
+def test_maximum_size_unit(z):
+    # one unit of ZGPU_MAX_UNIT_BYTES (256 MiB), resident on the device: cut into pieces by
+    # default; every piece boundary, block boundary and ring wrap on the way is checked by
+    # inflating the whole stream (on the CPU: one stream is serial work)
+    import torch
+    import bench
+    N = z._native
+    dev = torch.device("cuda:0")
+    data = bench.gen_units(4096, 65536, 31, dev)
+    n = data.numel()
+    assert n == 256 << 20
+    in_off = np.array([0, n], dtype=np.uint64)
+    host = data.cpu().numpy()
+    plan = z.Plan(in_off, 2, 0, N.F_FINAL_EACH | N.F_WANT_CRC)
+    out = torch.empty(plan.out_bound + 64, dtype=torch.uint8, device=dev)
+    plan.run(data.data_ptr(), out.data_ptr(), out.numel(), None)
+    off, crc, _ = plan.fetch(want_crc=True)
+    assert 0 < int(off[1]) <= z.deflate_bound(n)
+    got, used = zo.inflate_raw(out[:int(off[1])].cpu().numpy(), n, want_used=True)
+    assert used == int(off[1]) and got == host.tobytes()
+    del got
+    assert int(crc[0]) == N.checksum_device(data.data_ptr(), n)[0]
+    del plan
+    # a quarter of it as one piece (one workgroup walks 64 MiB: 1024 blocks, 1024 ring wraps)
+    q = 64 << 20
+    try:
+        N.set_split(0)
+        in_off = np.array([0, q], dtype=np.uint64)
+        plan = z.Plan(in_off, 2, 0, N.F_FINAL_EACH)
+        plan.run(data.data_ptr(), out.data_ptr(), out.numel(), None)
+        off1, _, _ = plan.fetch()
+        got, used = zo.inflate_raw(out[:int(off1[1])].cpu().numpy(), q, want_used=True)
+        assert used == int(off1[1]) and got == host[:q].tobytes()
+    finally:
+        N.set_split(1 << 20)
