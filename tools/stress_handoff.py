@@ -37,18 +37,24 @@ d_in_off = torch.from_numpy(in_off.astype(np.int64)).to(dev)
 bad_total = 0
 t0 = time.time()
 for rep in range(reps):
-    chain, nice, ctype = [(1, 8, 1), (1, 3, 2), (2, 32, 2), (8, 32, 2)][rep % 4]
+    N = z._native
+    chain, nice, ctype, lazy, flags = [
+        (1, 8, 1, 0, N.F_FINAL_EACH), (1, 3, 2, 0, N.F_FINAL_EACH), (2, 32, 2, 0, N.F_FINAL_EACH),
+        (8, 32, 2, 0, N.F_FINAL_EACH), (8, 258, 2, 0, N.F_FINAL_EACH), (3, 32, 1, 8, N.F_FINAL_EACH),
+        (8, 32, 2, 0, N.F_SYNC_ALIGN | N.F_FINAL_LAST | N.F_PRIME_WINDOW), (1, 258, 2, 4, N.F_SYNC_ALIGN | N.F_FINAL_LAST | N.F_PRIME_WINDOW),
+    ][rep % 8]
     z.set_search(chain, nice)
-    plan = z.Plan(in_off, ctype, 0, z._native.F_FINAL_EACH)
+    plan = z.Plan(in_off, ctype, lazy, flags)
     out = torch.empty(plan.out_bound + 64, dtype=torch.uint8, device=dev)
     plan.run(data.data_ptr(), out.data_ptr(), out.numel(), None)
     off, _, _ = plan.fetch()
-    st = gv.verify(out, torch.from_numpy(off.astype(np.int64)).to(dev), data, d_in_off, True)
+    st = gv.verify(out, torch.from_numpy(off.astype(np.int64)).to(dev), data, d_in_off,
+                   final_each=bool(flags & N.F_FINAL_EACH), primed=bool(flags & N.F_PRIME_WINDOW))
     bad = (st != 0).nonzero().flatten().tolist()
     bad_total += len(bad)
     if bad or rep % 10 == 0:
-        print("rep %d chain %d nice %d ctype %d: %d units, bad %s (%.0f s)" % (
-            rep, chain, nice, ctype, in_off.size - 1, [(u, int(in_off[u + 1] - in_off[u])) for u in bad[:5]],
+        print("rep %d chain %d nice %d ctype %d lazy %d flags %d: %d units, bad %s (%.0f s)" % (
+            rep, chain, nice, ctype, lazy, flags, in_off.size - 1, [(u, int(in_off[u + 1] - in_off[u])) for u in bad[:5]],
             time.time() - t0), flush=True)
     del plan, out
 z.set_search(8, 32)
