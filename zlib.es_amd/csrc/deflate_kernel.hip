@@ -647,13 +647,20 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 for (int w = 1; w < WG / 64; ++w) m = o[w] < m ? o[w] : m;
                 return m + NSLOT_E;
             };
+            // The frontier is one lane's serial work and every wave's start waits on it (LAG), so
+            // its loop is kept to one LDS round trip per item: the stamp of the next item is
+            // fetched together with the exit and count of the current one.  The LDS executes a
+            // wave's instructions in order, so the stores that end a turn (state, M_PARSE,
+            // unlock) need no waits between them.
             auto try_advance = [&]() {
                 if (lane == 0) {
                     for (;;) {
                         if (atomicCAS(&misc[M_LOCK], 0u, 1u) != 0u) break;  // someone else is at it
-                        uint32_t f = misc[M_PARSE], e = misc[M_ENTRY], t = misc[M_NTOK], safe = misc[M_SAFE];
+                        uint32_t f = lds_ld(&misc[M_PARSE]), e = lds_ld(&misc[M_ENTRY]), t = lds_ld(&misc[M_NTOK]),
+                                 safe = lds_ld(&misc[M_SAFE]);
+                        uint32_t stamp = lds_ld(&slot_done[f & (NSLOT - 1)]);
                         bool held = false;  // stopped by the bound, not by an unsearched item
-                        while (lds_ld(&slot_done[f & (NSLOT - 1)]) == f + 1) {
+                        while (stamp == f + 1) {
                             if (f == safe) {
                                 safe = safe_bound();
                                 if (f == safe) {
@@ -664,18 +671,17 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             const uint32_t sl = f & (NSLOT - 1), le = e - (f << 6);
                             slot_entry[f & (NSLOT_E - 1)] = e;
                             slot_tokb[f & (NSLOT_E - 1)] = t;
+                            stamp = lds_ld(&slot_done[(f + 1) & (NSLOT - 1)]);
                             if (le < 64u) {
                                 e = (f << 6) + exit_tab[sl * 64 + le];
                                 t += cnt_tab[sl * 64 + le];
                             }
                             ++f;
                         }
-                        misc[M_ENTRY] = e;
-                        misc[M_NTOK] = t;
-                        misc[M_SAFE] = safe;
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        lds_st(&misc[M_ENTRY], e);
+                        lds_st(&misc[M_NTOK], t);
+                        lds_st(&misc[M_SAFE], safe);
                         lds_st(&misc[M_PARSE], f);
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         lds_st(&misc[M_LOCK], 0u);
                         // an item stamped while the lock was held must not be left behind; nor a
                         // bound that moved (a wave that moves it after this look finds M_PARSE
