@@ -1,0 +1,55 @@
+"""Streams the GPU path produced (tests/golden/gpu_streams.json, written by
+tools/make_gpu_streams.py on an MI355X) against decoders that never saw the encoder:
+the oracle's strict inflater everywhere, and -- in the build container, where the reference
+tree and Node are present -- the reference's own RawInflate / Inflate / Gunzip / Unzip
+(tests/golden/check_gpu_streams.mjs).  No GPU is needed: the fixture is data."""
+import base64
+import hashlib
+import io
+import json
+import os
+import shutil
+import subprocess
+import zipfile
+
+import pytest
+
+import _oracle as zo
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIX = os.path.join(HERE, "golden", "gpu_streams.json")
+REF = "/root/reference"
+
+
+def _streams():
+    return json.load(open(FIX))["streams"]
+
+
+def test_fixture_covers_the_containers():
+    kinds = {}
+    for s in _streams():
+        kinds[s["kind"]] = kinds.get(s["kind"], 0) + 1
+    assert kinds["raw"] >= 20 and kinds["zlib"] >= 10 and kinds["gzip"] >= 10 and kinds["zip"] >= 1
+
+
+def test_gpu_streams_decode_with_the_oracle():
+    for s in _streams():
+        comp = base64.b64decode(s["b64"])
+        if s["kind"] == "zip":
+            with zipfile.ZipFile(io.BytesIO(comp)) as zf:
+                assert zf.testzip() is None
+                for e in s["entries"]:
+                    assert hashlib.sha256(zf.read(e["name"])).hexdigest() == e["sha256"]
+            continue
+        got = {"raw": zo.inflate_raw, "zlib": zo.inflate_zlib, "gzip": zo.gunzip}[s["kind"]](comp, s["n"])
+        assert len(got) == s["n"] and hashlib.sha256(got).hexdigest() == s["sha256"], (s["kind"], s.get("spec"))
+
+
+@pytest.mark.skipif(shutil.which("node") is None or not os.path.isdir(os.path.join(REF, "src")),
+                    reason="needs Node and the reference tree (build container only)")
+def test_gpu_streams_decode_with_the_reference_decoders():
+    r = subprocess.run(["node", os.path.join(HERE, "golden", "check_gpu_streams.mjs"), REF], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["ok"] == res["streams"] and not res["bad"]
