@@ -198,6 +198,9 @@ def main():
                            "traffic": measured_traffic(nu, ub, args),
                            "kernel": "zgpu_deflate_kernel + zgpu_emit_kernel", "kernel_ms": round(k_ms, 3),
                            "search_kernel_ms": round(search_ms, 3), "emit_kernel_ms": round(emit_ms, 3)}
+        lds = measured_lds(nu, ub, args)
+        if lds:
+            res["search_kernel_occupancy"] = lds  # what actually bounds the path: VALU issue and the LDS pipe
         res.update(verify_all(data, in_off, out, out_off, dev))
         if world == 1 and not args.no_cpu:
             res.update(cpu_leg(args, data, out, out_off, nu, ub))
@@ -218,6 +221,19 @@ def measured_traffic(nu, ub, args):
     if (w.get("units"), w.get("unit_bytes"), w.get("ctype"), w.get("lazy")) != (nu, ub, args.ctype, args.lazy):
         return None
     return t.get("bytes_per_launch")
+
+
+def measured_lds(nu, ub, args):
+    """LDS-pipe and VALU occupancy of the search kernel from the same committed counter passes
+    (measured on 8192 units of this mix), or None for another workload."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except (OSError, ValueError):
+        return None
+    w = t.get("workload", {})
+    if (w.get("unit_bytes"), w.get("ctype"), w.get("lazy")) != (ub, args.ctype, args.lazy):
+        return None
+    return t.get("lds")
 
 
 def verify_all(data, in_off, out, out_off, dev):

@@ -72,6 +72,26 @@ def main():
                     "stream between the two kernels is part of it",
             "source": "%s_pmc.json" % tag,
         }
+        # LDS side of the search kernel (sq1 / sq2 passes, 8192 units of the same mix): share of the
+        # kernel's cycles in which a CU's LDS pipe was busy, and in which it replayed bank conflicts.
+        # SQ_BUSY_CYCLES is summed over the 32 shader engines; 256 CUs.
+        try:
+            q1, q2 = out["sq1"]["zgpu_deflate_kernel"], out["sq2"]["zgpu_deflate_kernel"]
+            cu_cycles = q1["SQ_BUSY_CYCLES"] / 32.0 * 256.0
+            nbytes = 8192 * 65536
+            traffic["lds"] = {
+                "kernel": "zgpu_deflate_kernel",
+                "lds_pipe_busy_frac": round(q2["SQ_LDS_IDX_ACTIVE"] / cu_cycles, 4),
+                "lds_bank_conflict_frac": round(q2["SQ_LDS_BANK_CONFLICT"] / cu_cycles, 4),
+                "lds_wave_insts_per_input_byte": round(q1["SQ_INSTS_LDS"] / nbytes, 3),
+                "valu_wave_insts_per_input_byte": round(q1["SQ_INSTS_VALU"] / nbytes, 3),
+                "valu_busy_frac": round(4.0 * q1["SQ_INSTS_VALU"] / q1["SQ_WAVE_CYCLES"], 4),
+                "note": "SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT over CU-cycles (SQ_BUSY_CYCLES / 32 SEs x 256 CUs); "
+                        "VALU: a wave instruction holds its SIMD for 4 cycles; SQ_WAVE_CYCLES counts 4-cycle units summed "
+                        "over the 4 waves a SIMD holds, so SIMD-cycles = SQ_WAVE_CYCLES and busy = 4 x SQ_INSTS_VALU / SQ_WAVE_CYCLES",
+            }
+        except KeyError:
+            pass
         with open(os.path.join(DST, "traffic.json"), "w") as f:
             json.dump(traffic, f, indent=1)
     except KeyError:
