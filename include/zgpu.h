@@ -81,12 +81,11 @@ int zgpu_last_hip_error(void);
  * default; (8, 258) costs about 40 % of the speed and makes highly repetitive
  * input up to 15 % smaller. */
 int zgpu_set_search(int max_chain, int nice_length);
-/* In a batch too small to keep every compute unit busy, a unit longer than two
- * pieces is cut into pieces (batch bytes / 4 / compute units, at least 128 KiB,
- * at most piece_bytes) which are compressed side by side as chunks of the
- * unit's one stream (each ends
- * byte-aligned with an empty stored block; its window is primed with the
- * 32 KiB before it), so that one long input -- one RawDeflate#compress() call
+/* In a batch of fewer than 16 units per compute unit, a unit longer than two
+ * pieces is cut into pieces (batch bytes / 16 / compute units, at least
+ * 128 KiB, at most piece_bytes) which are compressed side by side as chunks of
+ * the unit's one stream (each ends byte-aligned with an empty stored block; its
+ * window is primed with the 32 KiB before it), so that one long input -- one RawDeflate#compress() call
  * on a large buffer, src/rawdeflate.js:102-124 -- uses the whole GPU instead of
  * one compute unit.  The unit's output is still one stream at one offset.
  * Default 1 MiB; at least 1 MiB; 0 = never cut.  Results do not depend on the

@@ -341,11 +341,13 @@ int zgpu_plan_create(zgpu_plan **out, const uint64_t *in_off, uint32_t n_units, 
     // A unit's pieces are consecutive, so its output is their concatenation.
     const bool chunked = (flags & ZGPU_F_SYNC_ALIGN) && !(flags & ZGPU_F_FINAL_EACH);
     const bool prime_units = chunked && (flags & ZGPU_F_PRIME_WINDOW);
-    // Piece size: a batch with fewer units than keep the CUs busy four times over cuts units longer
-    // than two pieces into pieces of total / (4 x CUs) bytes, between 128 KiB and the set limit.
+    // Piece size: a batch with fewer units than kPiecesPerCu per CU (the unit queue then balances
+    // poorly at its tail, and the emit kernel's workgroups run short) cuts units longer than two
+    // pieces into pieces of total / (kPiecesPerCu x CUs) bytes, between 128 KiB and the set limit.
+    constexpr uint32_t kPiecesPerCu = 16;
     uint64_t piece = 0;
-    if (ctype != ZGPU_NONE && g_split_bytes && n_units < 4u * (uint32_t)ds->cus) {
-        piece = align_up((in_off[n_units] - in_off[0]) / (4ull * (uint64_t)ds->cus) + 1, 65536);
+    if (ctype != ZGPU_NONE && g_split_bytes && n_units < kPiecesPerCu * (uint32_t)ds->cus) {
+        piece = align_up((in_off[n_units] - in_off[0]) / ((uint64_t)kPiecesPerCu * (uint64_t)ds->cus) + 1, 65536);
         if (piece < (128u << 10)) piece = 128u << 10;
         if (piece > g_split_bytes) piece = g_split_bytes;
     }
