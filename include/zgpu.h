@@ -117,6 +117,22 @@ int zgpu_deflate_batch(const uint8_t *in, const uint64_t *in_off, uint32_t n_uni
                        uint8_t *out, uint64_t out_cap, uint64_t *out_off,
                        uint32_t *crc32, uint32_t *adler32);
 
+/* The same call in two steps, for callers that allocate the output only once its
+ * size is known (the N-API addon fills a JS-owned ArrayBuffer of exactly that
+ * size; the reference grows its buffer as it writes, src/bitstream.js:30-35).
+ * begin uploads, compresses and reports the total compressed size; the bytes wait
+ * on the device.  finish copies them and the per-unit results into the caller's
+ * memory (out_cap >= that size) and always releases the job, also when it returns
+ * an error.  A job that is not finished is released with zgpu_job_release.
+ * Per-unit checksums are produced when flags carry ZGPU_F_WANT_CRC /
+ * ZGPU_F_WANT_ADLER. */
+typedef struct zgpu_job zgpu_job;
+int zgpu_deflate_batch_begin(const uint8_t *in, const uint64_t *in_off, uint32_t n_units, int ctype, int lazy,
+                             uint32_t flags, zgpu_job **job, uint64_t *out_total);
+int zgpu_deflate_batch_finish(zgpu_job *job, uint8_t *out, uint64_t out_cap, uint64_t *out_off,
+                              uint32_t *crc32, uint32_t *adler32);
+void zgpu_job_release(zgpu_job *job);
+
 /* ---- RawDeflate, device-resident plan ------------------------------------
  * Same operation with inputs and outputs resident in HBM.  A plan holds the
  * unit table and workspace on the device it was created on and can be run

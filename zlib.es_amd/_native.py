@@ -19,7 +19,8 @@ F_FINAL_EACH, F_SYNC_ALIGN, F_FINAL_LAST, F_PRIME_WINDOW, F_WANT_CRC, F_WANT_ADL
 SYMBOLS = [
     "zgpu_init", "zgpu_shutdown", "zgpu_strerror", "zgpu_last_hip_error", "zgpu_set_search", "zgpu_set_split",
     "zgpu_set_min_lazy",
-    "zgpu_deflate_bound", "zgpu_deflate_batch", "zgpu_plan_create", "zgpu_plan_destroy",
+    "zgpu_deflate_bound", "zgpu_deflate_batch", "zgpu_deflate_batch_begin", "zgpu_deflate_batch_finish",
+    "zgpu_job_release", "zgpu_plan_create", "zgpu_plan_destroy",
     "zgpu_plan_out_bound", "zgpu_plan_run", "zgpu_plan_out_off_device", "zgpu_plan_crc_device",
     "zgpu_plan_adler_device", "zgpu_plan_fetch", "zgpu_plan_kernel_ms", "zgpu_plan_phase_ms", "zgpu_checksum",
     "zgpu_checksum_device", "zgpu_crc32_update", "zgpu_adler32_update", "zgpu_checksum_kernel_ms",
@@ -63,6 +64,12 @@ def lib():
     L.zgpu_deflate_bound.argtypes = [u64]
     L.zgpu_deflate_batch.restype = i32
     L.zgpu_deflate_batch.argtypes = [vp, vp, u32, i32, i32, u32, vp, u64, vp, vp, vp]
+    L.zgpu_deflate_batch_begin.restype = i32
+    L.zgpu_deflate_batch_begin.argtypes = [vp, vp, u32, i32, i32, u32, C.POINTER(vp), C.POINTER(u64)]
+    L.zgpu_deflate_batch_finish.restype = i32
+    L.zgpu_deflate_batch_finish.argtypes = [vp, vp, u64, vp, vp, vp]
+    L.zgpu_job_release.restype = None
+    L.zgpu_job_release.argtypes = [vp]
     L.zgpu_plan_create.restype = i32
     L.zgpu_plan_create.argtypes = [C.POINTER(vp), vp, u32, i32, i32, u32]
     L.zgpu_plan_destroy.restype = None
@@ -183,15 +190,18 @@ def deflate_batch(units, ctype=DYNAMIC, lazy=0, flags=F_FINAL_EACH, want_crc=Fal
     off[1:] = np.cumsum([a.size for a in arrs], dtype=np.uint64)
     total = int(off[-1])
     flat = np.concatenate(arrs) if total else np.zeros(1, dtype=np.uint8)
-    cap = sum(deflate_bound(a.size) + 48 for a in arrs) + 64
-    out = np.empty(cap, dtype=np.uint8)
     out_off = np.zeros(n + 1, dtype=np.uint64)
     crc = np.zeros(n, dtype=np.uint32) if want_crc else None
     adl = np.zeros(n, dtype=np.uint32) if want_adler else None
-    rc = lib().zgpu_deflate_batch(
-        flat.ctypes.data, off.ctypes.data, n, ctype, lazy, flags, out.ctypes.data, cap,
-        out_off.ctypes.data, crc.ctypes.data if want_crc else None, adl.ctypes.data if want_adler else None)
-    _check(rc, "zgpu_deflate_batch")
+    # two steps: the output is allocated once its size is known
+    job, total = C.c_void_p(None), C.c_uint64(0)
+    flags |= (F_WANT_CRC if want_crc else 0) | (F_WANT_ADLER if want_adler else 0)
+    _check(lib().zgpu_deflate_batch_begin(flat.ctypes.data, off.ctypes.data, n, ctype, lazy, flags, C.byref(job),
+                                          C.byref(total)), "zgpu_deflate_batch_begin")
+    out = np.empty(max(1, total.value), dtype=np.uint8)
+    rc = lib().zgpu_deflate_batch_finish(job, out.ctypes.data, out.size, out_off.ctypes.data,
+                                         crc.ctypes.data if want_crc else None, adl.ctypes.data if want_adler else None)
+    _check(rc, "zgpu_deflate_batch_finish")
     res = [out[int(out_off[i]):int(out_off[i + 1])].tobytes() for i in range(n)]
     return res, (crc.tolist() if want_crc else None), (adl.tolist() if want_adler else None)
 

@@ -226,6 +226,15 @@ struct zgpu_plan {
     bool ran = false;
 };
 
+// a host-buffer batch between its two calls: results fetched, compressed bytes still on the device
+struct zgpu_job {
+    int device = -1;
+    zgpu_plan *plan = nullptr;
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    std::vector<uint64_t> out_off;
+    std::vector<uint32_t> crc, adler;
+};
+
 namespace {
 uint64_t unit_blocks(uint64_t n) { return n ? (n + ZGPU_BLOCK_BYTES - 1) / ZGPU_BLOCK_BYTES : 1; }
 // tokens reserved for a unit: full blocks at their fixed stride, the last one exact (even)
@@ -625,48 +634,109 @@ int zgpu_plan_phase_ms(zgpu_plan *p, float *search_ms, float *emit_ms) {
     return ZGPU_OK;
 }
 
-int zgpu_deflate_batch(const uint8_t *in, const uint64_t *in_off, uint32_t n_units, int ctype, int lazy,
-                       uint32_t flags, uint8_t *out, uint64_t out_cap, uint64_t *out_off,
-                       uint32_t *crc32, uint32_t *adler32) {
-    if (!in_off || !out || !out_off) return ZGPU_E_ARG;
+int zgpu_deflate_batch_begin(const uint8_t *in, const uint64_t *in_off, uint32_t n_units, int ctype, int lazy,
+                             uint32_t flags, zgpu_job **job_out, uint64_t *out_total) {
+    if (!in_off || !job_out || !out_total) return ZGPU_E_ARG;
+    *job_out = nullptr;
     HostDeviceScope scope;
     if (scope.rc) return scope.rc;
-    if (crc32) flags |= ZGPU_F_WANT_CRC;
-    if (adler32) flags |= ZGPU_F_WANT_ADLER;
-    zgpu_plan *p = nullptr;
-    int rc = zgpu_plan_create(&p, in_off, n_units, ctype, lazy, flags);
-    if (rc) return rc;
-    const uint64_t base = in_off[0], total = in_off[n_units] - base;
-    uint8_t *d_in = nullptr, *d_out = nullptr;
+    auto *j = new (std::nothrow) zgpu_job();
+    if (!j) return ZGPU_E_NOMEM;
     auto fail = [&](int code) {
-        (void)hipFree(d_in);
-        (void)hipFree(d_out);
-        zgpu_plan_destroy(p);
+        zgpu_job_release(j);
         return code;
     };
+    if (hipGetDevice(&j->device) != hipSuccess) return fail(ZGPU_E_NODEVICE);
+    int rc = zgpu_plan_create(&j->plan, in_off, n_units, ctype, lazy, flags);
+    if (rc) return fail(rc);
+    zgpu_plan *p = j->plan;
+    const uint64_t base = in_off[0], total = in_off[n_units] - base;
+    if (total && !in) return fail(ZGPU_E_ARG);
     hipError_t e;
     // The plan indexes its input with the caller's absolute offsets: only the bytes of the
     // units are allocated and copied, and the base pointer handed to the plan is moved back by
     // the first offset (kept congruent modulo 256 so the kernels see the caller's alignment).
     const uint64_t lead = base & 255u;
-    if ((e = hipMalloc(&d_in, lead + total + 64)) != hipSuccess) { g_last_hip = e; return fail(ZGPU_E_NOMEM); }
-    if ((e = hipMalloc(&d_out, p->out_bound + 64)) != hipSuccess) { g_last_hip = e; return fail(ZGPU_E_NOMEM); }
-    if (total && (e = hipMemcpy(d_in + lead, in + base, total, hipMemcpyHostToDevice)) != hipSuccess) {
+    if ((e = hipMalloc(&j->d_in, lead + total + 64)) != hipSuccess) { g_last_hip = e; return fail(ZGPU_E_NOMEM); }
+    if ((e = hipMalloc(&j->d_out, p->out_bound + 64)) != hipSuccess) { g_last_hip = e; return fail(ZGPU_E_NOMEM); }
+    if (total && (e = hipMemcpy(j->d_in + lead, in + base, total, hipMemcpyHostToDevice)) != hipSuccess) {
         g_last_hip = e;
         return fail(ZGPU_E_NODEVICE);
     }
-    const uint8_t *d_in0 = (const uint8_t *)((uintptr_t)d_in + lead - base);
-    rc = zgpu_plan_run(p, d_in0, d_out, p->out_bound, nullptr);
+    const uint8_t *d_in0 = (const uint8_t *)((uintptr_t)j->d_in + lead - base);
+    rc = zgpu_plan_run(p, d_in0, j->d_out, p->out_bound, nullptr);
     if (rc) return fail(rc);
-    rc = zgpu_plan_fetch(p, out_off, crc32, adler32, nullptr);
-    if (rc) return fail(rc);
-    if (out_off[n_units] > out_cap) return fail(ZGPU_E_OUTCAP);
-    if (out_off[n_units] &&
-        (e = hipMemcpy(out, d_out, out_off[n_units], hipMemcpyDeviceToHost)) != hipSuccess) {
-        g_last_hip = e;
-        return fail(ZGPU_E_NODEVICE);
+    try {
+        j->out_off.resize((size_t)n_units + 1);
+        if (flags & ZGPU_F_WANT_CRC) j->crc.resize(n_units);
+        if (flags & ZGPU_F_WANT_ADLER) j->adler.resize(n_units);
+    } catch (const std::bad_alloc &) {
+        return fail(ZGPU_E_NOMEM);
     }
-    return fail(ZGPU_OK);
+    rc = zgpu_plan_fetch(p, j->out_off.data(), j->crc.empty() ? nullptr : j->crc.data(),
+                         j->adler.empty() ? nullptr : j->adler.data(), nullptr);
+    if (rc) return fail(rc);
+    // the workspace is no longer needed; the compressed bytes wait on the device
+    zgpu_plan_destroy(j->plan);
+    j->plan = nullptr;
+    (void)hipFree(j->d_in);
+    j->d_in = nullptr;
+    *out_total = j->out_off[n_units];
+    *job_out = j;
+    return ZGPU_OK;
+}
+
+int zgpu_deflate_batch_finish(zgpu_job *j, uint8_t *out, uint64_t out_cap, uint64_t *out_off, uint32_t *crc32,
+                              uint32_t *adler32) {
+    if (!j) return ZGPU_E_ARG;
+    int rc = ZGPU_OK;
+    const size_t n = j->out_off.size() - 1;
+    const uint64_t total = j->out_off[n];
+    if (!out_off || (total && !out) || (crc32 && j->crc.empty()) || (adler32 && j->adler.empty())) {
+        rc = ZGPU_E_ARG;
+    } else if (total > out_cap) {
+        rc = ZGPU_E_OUTCAP;
+    } else {
+        int cur = 0;
+        const bool moved = hipGetDevice(&cur) == hipSuccess && cur != j->device && hipSetDevice(j->device) == hipSuccess;
+        hipError_t e = total ? hipMemcpy(out, j->d_out, total, hipMemcpyDeviceToHost) : hipSuccess;
+        if (moved) (void)hipSetDevice(cur);
+        if (e != hipSuccess) {
+            g_last_hip = e;
+            rc = ZGPU_E_NODEVICE;
+        } else {
+            memcpy(out_off, j->out_off.data(), (n + 1) * sizeof(uint64_t));
+            if (crc32) memcpy(crc32, j->crc.data(), n * sizeof(uint32_t));
+            if (adler32) memcpy(adler32, j->adler.data(), n * sizeof(uint32_t));
+        }
+    }
+    zgpu_job_release(j);
+    return rc;
+}
+
+void zgpu_job_release(zgpu_job *j) {
+    if (!j) return;
+    int cur = 0;
+    const bool moved = j->device >= 0 && hipGetDevice(&cur) == hipSuccess && cur != j->device &&
+                       hipSetDevice(j->device) == hipSuccess;
+    zgpu_plan_destroy(j->plan);
+    (void)hipFree(j->d_in);
+    (void)hipFree(j->d_out);
+    if (moved) (void)hipSetDevice(cur);
+    delete j;
+}
+
+int zgpu_deflate_batch(const uint8_t *in, const uint64_t *in_off, uint32_t n_units, int ctype, int lazy,
+                       uint32_t flags, uint8_t *out, uint64_t out_cap, uint64_t *out_off,
+                       uint32_t *crc32, uint32_t *adler32) {
+    if (!in_off || !out || !out_off) return ZGPU_E_ARG;
+    if (crc32) flags |= ZGPU_F_WANT_CRC;
+    if (adler32) flags |= ZGPU_F_WANT_ADLER;
+    zgpu_job *job = nullptr;
+    uint64_t total = 0;
+    int rc = zgpu_deflate_batch_begin(in, in_off, n_units, ctype, lazy, flags, &job, &total);
+    if (rc) return rc;
+    return zgpu_deflate_batch_finish(job, out, out_cap, out_off, crc32, adler32);
 }
 
 // ---- checksums -------------------------------------------------------------

@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -17,6 +19,8 @@ namespace {
 
 typedef int (*fn_deflate_batch)(const uint8_t *, const uint64_t *, uint32_t, int, int, uint32_t, uint8_t *,
                                 uint64_t, uint64_t *, uint32_t *, uint32_t *);
+typedef int (*fn_batch_begin)(const uint8_t *, const uint64_t *, uint32_t, int, int, uint32_t, void **, uint64_t *);
+typedef int (*fn_batch_finish)(void *, uint8_t *, uint64_t, uint64_t *, uint32_t *, uint32_t *);
 typedef int (*fn_checksum)(const uint8_t *, uint64_t, uint32_t *, uint32_t *);
 typedef uint64_t (*fn_bound)(uint64_t);
 typedef uint32_t (*fn_combine)(uint32_t, uint32_t, uint64_t);
@@ -27,6 +31,8 @@ typedef int (*fn_set1)(int);
 struct Lib {
     void *h = nullptr;
     fn_deflate_batch deflate_batch = nullptr;
+    fn_batch_begin batch_begin = nullptr;
+    fn_batch_finish batch_finish = nullptr;
     fn_checksum checksum = nullptr;
     fn_bound bound = nullptr;
     fn_combine crc_combine = nullptr, adler_combine = nullptr;
@@ -72,6 +78,8 @@ napi_value Init_(napi_env env, napi_callback_info info) {
         return nullptr;
     }
     g.deflate_batch = (fn_deflate_batch)dlsym(h, "zgpu_deflate_batch");
+    g.batch_begin = (fn_batch_begin)dlsym(h, "zgpu_deflate_batch_begin");
+    g.batch_finish = (fn_batch_finish)dlsym(h, "zgpu_deflate_batch_finish");
     g.checksum = (fn_checksum)dlsym(h, "zgpu_checksum");
     g.bound = (fn_bound)dlsym(h, "zgpu_deflate_bound");
     g.crc_combine = (fn_combine)dlsym(h, "zgpu_crc32_combine");
@@ -80,7 +88,7 @@ napi_value Init_(napi_env env, napi_callback_info info) {
     g.set_search = (fn_set2)dlsym(h, "zgpu_set_search");
     g.set_min_lazy = (fn_set1)dlsym(h, "zgpu_set_min_lazy");
     g.set_split = (int (*)(uint64_t))dlsym(h, "zgpu_set_split");
-    if (!g.deflate_batch || !g.checksum || !g.bound || !g.crc_combine || !g.adler_combine || !g.strerror_ ||
+    if (!g.deflate_batch || !g.batch_begin || !g.batch_finish || !g.checksum || !g.bound || !g.crc_combine || !g.adler_combine || !g.strerror_ ||
         !g.set_search || !g.set_min_lazy || !g.set_split) {
         dlclose(h);
         napi_throw_error(env, nullptr, "libzgpu.so lacks an expected symbol");
@@ -134,7 +142,6 @@ napi_value DeflateBatch(napi_env env, napi_callback_info info) {
     if (n) {
         std::vector<uint64_t> in_off(n + 1, 0), out_off(n + 1, 0);
         std::vector<const uint8_t *> ptrs(n);
-        uint64_t cap = 64;
         for (uint32_t i = 0; i < n; ++i) {
             napi_value e;
             NAPI_OK(napi_get_element(env, argv[0], i, &e));
@@ -144,20 +151,45 @@ napi_value DeflateBatch(napi_env env, napi_callback_info info) {
                 return nullptr;
             }
             in_off[i + 1] = in_off[i] + len;
-            cap += g.bound(len) + 48;
         }
-        std::vector<uint8_t> flat(in_off[n] ? in_off[n] : 1);
-        for (uint32_t i = 0; i < n; ++i)
-            if (in_off[i + 1] > in_off[i]) memcpy(flat.data() + in_off[i], ptrs[i], in_off[i + 1] - in_off[i]);
-        std::vector<uint8_t> out(cap);
+        // Inputs that already lie back to back in memory (one input; subarrays of one buffer,
+        // as the chunked helpers pass) are handed over in place; anything else is gathered
+        // into one staging buffer.  Neither buffer is cleared first.
+        const uint8_t *first = nullptr;  // where input 0 would start if all of them lie back to back
+        bool contiguous = true;
+        for (uint32_t i = 0; i < n && contiguous; ++i) {
+            if (in_off[i + 1] == in_off[i]) continue;  // an empty input has no address to check
+            if (!first) first = ptrs[i] - in_off[i];
+            contiguous = ptrs[i] == first + in_off[i];
+        }
+        std::unique_ptr<uint8_t[]> flat;
+        const uint8_t *src = first;
+        if (!contiguous || !first) {
+            flat.reset(new (std::nothrow) uint8_t[in_off[n] ? in_off[n] : 1]);
+            if (!flat) return throw_zgpu(env, "staging buffer", -3);
+            for (uint32_t i = 0; i < n; ++i)
+                if (in_off[i + 1] > in_off[i]) memcpy(flat.get() + in_off[i], ptrs[i], in_off[i + 1] - in_off[i]);
+            src = flat.get();
+        }
+        // Two steps: compress, learn the size, then let the library copy from the device straight
+        // into a JS-owned ArrayBuffer of exactly that size (no intermediate buffer, no finalizer).
         std::vector<uint32_t> crc(want_crc ? n : 0), adler(want_adler ? n : 0);
-        int rc = g.deflate_batch(flat.data(), in_off.data(), n, ctype, lazy, flags, out.data(), cap, out_off.data(),
-                                 want_crc ? crc.data() : nullptr, want_adler ? adler.data() : nullptr);
-        if (rc) return throw_zgpu(env, "zgpu_deflate_batch", rc);
+        void *job = nullptr;
+        uint64_t total = 0;
+        int rc = g.batch_begin(src, in_off.data(), n, ctype, lazy,
+                               flags | (want_crc ? 16u : 0u) | (want_adler ? 32u : 0u), &job, &total);
+        if (rc) return throw_zgpu(env, "zgpu_deflate_batch_begin", rc);
+        flat.reset();
         void *ab_data = nullptr;
         napi_value ab;
-        NAPI_OK(napi_create_arraybuffer(env, out_off[n], &ab_data, &ab));
-        if (out_off[n]) memcpy(ab_data, out.data(), out_off[n]);
+        if (napi_create_arraybuffer(env, total, &ab_data, &ab) != napi_ok) {
+            g.batch_finish(job, nullptr, 0, nullptr, nullptr, nullptr);  // releases the job
+            napi_throw_error(env, nullptr, "cannot allocate the output ArrayBuffer");
+            return nullptr;
+        }
+        rc = g.batch_finish(job, (uint8_t *)ab_data, total, out_off.data(), want_crc ? crc.data() : nullptr,
+                            want_adler ? adler.data() : nullptr);
+        if (rc) return throw_zgpu(env, "zgpu_deflate_batch_finish", rc);
         for (uint32_t i = 0; i < n; ++i) {
             napi_value ta;
             NAPI_OK(napi_create_typedarray(env, napi_uint8_array, out_off[i + 1] - out_off[i], ab, out_off[i], &ta));

@@ -1,0 +1,26 @@
+// Throughput of the N-API path (host buffers, PCIe and JS object creation included).
+//   node zlib.es_amd/js/test/bench_addon.js
+'use strict';
+const { Zlib, deflateChunked } = require('../zlib_gpu.js');
+const n = 16384, ub = 65536;
+const big = new Uint8Array(n * ub);
+let x = 12345;
+for (let i = 0; i < big.length; ++i) {
+	if ((i & 7) === 0) x = (Math.imul(x, 1664525) + 1013904223) >>> 0;
+	big[i] = 97 + ((x >>> (4 * (i & 7))) & 15);
+}
+const views = [], copies = [];
+for (let i = 0; i < n; ++i) views.push(big.subarray(i * ub, (i + 1) * ub));
+for (let i = 0; i < n; i += 16) copies.push(big.slice(i * ub, (i + 1) * ub));
+function time(name, bytes, fn) {
+	fn();
+	const t = process.hrtime.bigint();
+	const r = fn();
+	const s = Number(process.hrtime.bigint() - t) / 1e9;
+	console.log(name + ': ' + (bytes / s / 1e9).toFixed(2) + ' GB/s (' + (s * 1e3).toFixed(1) + ' ms)');
+	return r;
+}
+time('compressBatch, 16384 x 64 KiB views of one buffer', n * ub, () => Zlib.RawDeflate.compressBatch(views, { compressionType: 2 }));
+time('compressBatch, 1024 separate 64 KiB buffers', copies.length * ub, () => Zlib.RawDeflate.compressBatch(copies, { compressionType: 2 }));
+time('deflateChunked, 1 GiB in 1 MiB chunks', n * ub, () => deflateChunked(big, { chunkSize: 1 << 20 }));
+time('RawDeflate#compress, one 64 MiB input', 64 << 20, () => new Zlib.RawDeflate(big.subarray(0, 64 << 20)).compress());

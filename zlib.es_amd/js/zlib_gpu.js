@@ -30,6 +30,16 @@ function asU8(input) {
 	throw new TypeError('unsupported input');
 }
 
+// The first `used` bytes of `body` followed by `extra` more: in place when body's buffer
+// has the room (the reference re-wraps result.buffer the same way, src/gzip.js:112-116,
+// src/deflate.js:87-93), else in a new buffer.  Always a view at byteOffset 0.
+function withTrailerRoom(body, used, extra) {
+	if (body.byteOffset === 0 && body.buffer.byteLength >= used + extra) return new Uint8Array(body.buffer, 0, used + extra);
+	const out = new Uint8Array(used + extra);
+	out.set(body.subarray(0, used));
+	return out;
+}
+
 class CRC32 {
 	// src/crc32.js:14-50
 	static calc(data, pos, length) {
@@ -110,7 +120,15 @@ class RawDeflate {
 	_gpuBlock(blockArray, ctype, isFinalBlock) {
 		const r = addon.deflateBatch([asU8(blockArray)], ctype, this.lazy | 0, isFinalBlock ? F_FINAL_EACH : F_SYNC_ALIGN, false, false);
 		const body = r.outputs[0];
-		const out = new Uint8Array(this.op + body.length); // view at byteOffset 0 of its own buffer
+		if (this.op === 0 && body.byteOffset === 0 && body.byteLength === body.buffer.byteLength) {
+			// nothing before it: the addon's buffer already is a view at byteOffset 0 of its own buffer
+			this.op = body.length;
+			this.output = body;
+			return body;
+		}
+		// view at byteOffset 0 of its own buffer, with room for the 8 trailer bytes the container
+		// classes append in place when the buffer allows (src/gzip.js:112-116, src/deflate.js:87-93)
+		const out = new Uint8Array(new ArrayBuffer(this.op + body.length + 8), 0, this.op + body.length);
 		out.set(this.output.subarray(0, this.op));
 		out.set(body, this.op);
 		this.op = out.length;
@@ -172,8 +190,7 @@ class Deflate {
 		this.rawDeflate.op = pos;
 		const body = this.rawDeflate.compress();
 		let pos2 = body.length;
-		const out = new Uint8Array(pos2 + 4);
-		out.set(body);
+		const out = withTrailerRoom(body, pos2, 4);
 		out[pos2++] = (adler >> 24) & 0xff;
 		out[pos2++] = (adler >> 16) & 0xff;
 		out[pos2++] = (adler >> 8) & 0xff;
@@ -234,8 +251,7 @@ class Gzip {
 		const rawdeflate = new RawDeflate(this.input, this.deflateOptions);
 		const body = rawdeflate.compress();
 		let op2 = rawdeflate.op;
-		const out = new Uint8Array(op2 + 8);
-		out.set(body.subarray(0, op2));
+		const out = withTrailerRoom(body, op2, 8);
 		const crc32 = CRC32.calc(this.input);
 		out[op2++] = crc32 & 0xff;
 		out[op2++] = (crc32 >>> 8) & 0xff;
