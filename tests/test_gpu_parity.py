@@ -193,6 +193,40 @@ def test_lazy_roundtrip_and_gain(z):
     assert s8 <= s0 and s32 <= s8 * 1.001
 
 
+def test_host_batch_in_two_steps(z):
+    import ctypes as C
+    N = z._native
+    L = N.lib()
+    units = [zo.gen({"gen": "text", "n": 50_000, "seed": 1}), np.zeros(0, dtype=np.uint8),
+             zo.gen({"gen": "rnd", "n": 3000, "seed": 2})]
+    flat = np.concatenate(units)
+    off = np.array([0, 50_000, 50_000, 53_000], dtype=np.uint64)
+
+    def begin(flags):
+        job, total = C.c_void_p(None), C.c_uint64(0)
+        assert L.zgpu_deflate_batch_begin(flat.ctypes.data, off.ctypes.data, 3, 2, 0, flags, C.byref(job), C.byref(total)) == 0
+        return job, total.value
+
+    want, crc_want, _ = z.deflate_batch(units, 2, 0, want_crc=True)
+    job, total = begin(N.F_FINAL_EACH | N.F_WANT_CRC)
+    assert total == sum(len(w) for w in want)
+    out = np.empty(total, dtype=np.uint8)
+    out_off = np.zeros(4, dtype=np.uint64)
+    crc = np.zeros(3, dtype=np.uint32)
+    assert L.zgpu_deflate_batch_finish(job, out.ctypes.data, total, out_off.ctypes.data, crc.ctypes.data, None) == 0
+    assert [out[int(a):int(b)].tobytes() for a, b in zip(out_off, out_off[1:])] == want and crc.tolist() == crc_want
+    # a buffer that is too small: error, and the job is gone all the same
+    job, total = begin(N.F_FINAL_EACH)
+    assert L.zgpu_deflate_batch_finish(job, out.ctypes.data, total - 1, out_off.ctypes.data, None, None) == -4
+    # checksums that were not asked for at begin cannot be fetched at finish
+    job, total = begin(N.F_FINAL_EACH)
+    assert L.zgpu_deflate_batch_finish(job, out.ctypes.data, total, out_off.ctypes.data, crc.ctypes.data, None) == -2
+    # a job that is dropped
+    job, total = begin(N.F_FINAL_EACH)
+    L.zgpu_job_release(job)
+    L.zgpu_job_release(None)
+
+
 def test_host_batch_with_nonzero_first_offset(z):
     # the units are a slice in the middle of a larger host buffer: offsets are absolute
     N = z._native
