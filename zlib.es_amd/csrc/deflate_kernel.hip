@@ -151,9 +151,6 @@ __device__ inline void load_ring(uint8_t *ring, const uint8_t *in, uint32_t lo, 
     }
 }
 
-// unaligned dword from LDS in one instruction (gfx950 supports unaligned DS access)
-typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-__device__ inline uint32_t ld4(const uint8_t *p) { return *(const u32_unaligned *)p; }
 
 // 16 bytes at any LDS address, and the number of leading bytes (0..16) in which
 // two such pieces agree.  An LDS access that is not naturally aligned to its
