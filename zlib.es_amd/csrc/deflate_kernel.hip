@@ -79,14 +79,14 @@ static_assert(L_TOTAL <= 163840, "LDS budget");
 
 // ---- LDS map of the emit kernel (bytes) --------------------------------------
 constexpr int EWG = 256;            // threads of an emit workgroup
-constexpr int ETOK = 2 * EWG;       // tokens per emission pass
+constexpr int ETOK = 4 * EWG;       // token slots per emission pass (a match takes two: at most 2 * EWG tokens of 48 bits)
 constexpr uint32_t E_FL = 0;                        // u32[288] + u32[32] block histograms
 constexpr uint32_t E_MISC = E_FL + 320 * 4;         // u32[64]
 constexpr uint32_t E_LLTAB = E_MISC + 64 * 4;       // u32[288] code | len<<16
 constexpr uint32_t E_DTAB = E_LLTAB + 288 * 4;      // u32[32]
 constexpr uint32_t E_STAGE = E_DTAB + 32 * 4;       // u32[STAGE_WORDS] bit staging
-constexpr int STAGE_WORDS = 1024;                   // >= header + ETOK * 48 / 32 + carry
-static_assert(STAGE_WORDS >= 160 + ETOK * 48 / 32 + 2, "staging capacity");
+constexpr int STAGE_WORDS = 1024;                   // >= header + (ETOK / 2) * 48 / 32 + carry
+static_assert(STAGE_WORDS >= 160 + (ETOK / 2) * 48 / 32 + 2, "staging capacity");
 constexpr uint32_t E_HUF = E_STAGE + STAGE_WORDS * 4;  // Huffman build scratch
 // Huffman build scratch map (bytes from E_HUF): the lit/len tree, then the
 // distance tree (reused for the code-length tree); once the lit/len and
@@ -519,8 +519,8 @@ __device__ void wave_huffman(const HufS &S, uint32_t m_in, uint32_t nsym, uint32
 struct Params {
     const uint8_t *in;
     const uint64_t *in_off;     // n_units+1
-    uint32_t *tok;              // token buffer of this round
-    const uint64_t *tok_off;    // n_units: first token of the unit within tok
+    uint16_t *tok;              // token slots of this round
+    const uint64_t *tok_off;    // n_units: first slot of the unit within tok
     const uint32_t *blk_first;  // n_units: index of the unit's first block
     uint32_t *hist;             // blocks x 320 symbol counts (lit/len 288, dist 32)
     uint32_t *ntok;             // blocks: tokens incl. end-of-block
@@ -564,7 +564,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
         const uint8_t *in = P.in + uoff - pr;
         const uint32_t n = n_unit + pr;
         const uint32_t prime_items = pr >> 6;
-        uint32_t *tokbuf = P.tok + P.tok_off[u];  // of the block in progress
+        uint16_t *tokbuf = P.tok + P.tok_off[u];  // of the block in progress
 
         // ---- unit init ----
         for (int i = tid; i < (1 << HBITS) / 8; i += WG)
@@ -758,19 +758,24 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 const unsigned long long two = path & __ballot(kind == 2);
                 const bool on = (path >> lane) & 1ull;
                 if (on) {
+                    // slots before this lane's: one per path position, one more per match, one
+                    // more per literal + match
+                    const unsigned long long mt = path & M;
                     const uint32_t idx =
                         __builtin_amdgcn_mbcnt_hi((uint32_t)(path >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)path, 0u)) +
+                        __builtin_amdgcn_mbcnt_hi((uint32_t)(mt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mt, 0u)) +
                         __builtin_amdgcn_mbcnt_hi((uint32_t)(two >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)two, 0u));
-                    uint32_t *dst = tokbuf + tokbase + idx;
+                    uint16_t *dst = tokbuf + tokbase + idx;
                     if (kind != 1) {
                         const uint32_t b = ring[(p0 + (uint32_t)lane) & (RING - 1)];
-                        *dst++ = b;
+                        *dst++ = (uint16_t)b;
                         atomicAdd(&fl[b], 1u);
                     }
                     if (kind != 0) {
                         const uint32_t t = kind == 1 ? ld : ldn;
                         const uint32_t tl = t >> 16, td = t & 0xffffu;
-                        *dst = 0x80000000u | (tl - 3) << 16 | (td - 1);
+                        dst[0] = (uint16_t)(0x8000u | (tl - 3));
+                        dst[1] = (uint16_t)(td - 1);
                         uint32_t sym, eb, ev;
                         len_sym(tl - 3, sym, eb, ev);
                         atomicAdd(&fl[sym], 1u);
@@ -951,7 +956,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     if (lane == 63) l1 = 0;
                     uint32_t J = successor(best_len, l1, kind);
                     if ((uint32_t)lane >= seg_end) J = (uint32_t)lane;  // past the end: stay put
-                    uint32_t Cn = (uint32_t)lane < seg_end ? (kind == 2 ? 2u : 1u) : 0u;
+                    uint32_t Cn = (uint32_t)lane < seg_end ? 1u + kind : 0u;  // slots: literal 1, match 2, literal + match 3
 #pragma unroll
                     for (int r = 0; r < 6; ++r) {
                         const int idx = (int)(J & 63u);
@@ -1019,7 +1024,7 @@ struct EParams {
     uint8_t *out_tmp;
     uint32_t *out_size;        // n_units
     uint32_t *status;          // n_units
-    const uint32_t *tok;       // token buffer of this round
+    const uint16_t *tok;       // token slots of this round
     const uint64_t *tok_off;   // n_units: first token of the unit within tok
     const uint32_t *blk_first; // n_units: index of the unit's first block
     const uint32_t *hist;      // blocks x 320 symbol counts (lit/len 288, dist 32)
@@ -1056,7 +1061,7 @@ zgpu_emit_kernel(EParams P) {
         for (int i = tid; i < STAGE_WORDS; i += EWG) stage[i] = 0;
         for (uint32_t blk = 0; blk < nblk; ++blk) {
             const uint32_t gb = P.blk_first[u] + blk;
-            const uint32_t *tokbuf = P.tok + P.tok_off[u] + (uint64_t)blk * ZGPU_BLOCK_TOK;
+            const uint16_t *tokbuf = P.tok + P.tok_off[u] + (uint64_t)blk * ZGPU_BLOCK_TOK;
             const uint32_t ntok = P.ntok[gb];
             const uint32_t bfinal = (blk + 1 == nblk && final_unit) ? 1u : 0u;
             for (int i = tid; i < 320; i += EWG) fl[i] = P.hist[(size_t)gb * 320 + i];
@@ -1336,30 +1341,31 @@ zgpu_emit_kernel(EParams P) {
             __syncthreads();
             bitpos = base_word * 32 + misc[M_TMP];
             __syncthreads();
-            // ---- emit tokens: two per thread and pass ----
+            // ---- emit tokens: four slots per thread and pass ----
             // bits of a pass are OR-merged into the staging words at their prefix-sum
             // offsets; full words leave with coalesced stores and are cleared by the
             // thread that stored them, the partial last word moves to the front.
-            auto tok_bits = [&](uint32_t tk, uint64_t &bits, uint32_t &nb) {
-                if (!(tk & 0x80000000u)) {
-                    const uint32_t e = lltab[tk];
-                    bits = e & 0xffff;
-                    nb = e >> 16;
-                } else {
-                    uint32_t sym, eb, ev;
-                    len_sym((tk >> 16) & 0xff, sym, eb, ev);
-                    uint32_t e = lltab[sym];
-                    bits = e & 0xffff;
-                    nb = e >> 16;
-                    bits |= (uint64_t)ev << nb;
-                    nb += eb;
-                    dist_sym(tk & 0xffff, sym, eb, ev);
-                    e = dtab[sym];
-                    bits |= (uint64_t)(e & 0xffff) << nb;
-                    nb += e >> 16;
-                    bits |= (uint64_t)ev << nb;
-                    nb += eb;
-                }
+            // A slot is a literal / end-of-block, the first half of a match (bit 15) or its
+            // second half (the slot before it has bit 15; a distance - 1 never has).
+            auto lit_bits = [&](uint32_t v, uint64_t &bits, uint32_t &nb) {
+                const uint32_t e = lltab[v];
+                bits = e & 0xffff;
+                nb = e >> 16;
+            };
+            auto match_bits = [&](uint32_t first, uint32_t second, uint64_t &bits, uint32_t &nb) {
+                uint32_t sym, eb, ev;
+                len_sym(first & 0xff, sym, eb, ev);
+                uint32_t e = lltab[sym];
+                bits = e & 0xffff;
+                nb = e >> 16;
+                bits |= (uint64_t)ev << nb;
+                nb += eb;
+                dist_sym(second, sym, eb, ev);
+                e = dtab[sym];
+                bits |= (uint64_t)(e & 0xffff) << nb;
+                nb += e >> 16;
+                bits |= (uint64_t)ev << nb;
+                nb += eb;
             };
             auto stage_or = [&](uint32_t rel, uint64_t bits, uint32_t nb) {
                 if (!nb) return;
@@ -1370,19 +1376,44 @@ zgpu_emit_kernel(EParams P) {
                 if (sh && (nb + sh > 64)) atomicOr(&stage[w + 2], (uint32_t)(bits >> (64 - sh)));
             };
             for (uint32_t t0 = 0; t0 < ntok; t0 += ETOK) {
-                uint64_t b0 = 0, b1 = 0;
-                uint32_t n0 = 0, n1 = 0;
-                const uint32_t ti = t0 + 2 * (uint32_t)tid;
+                uint64_t sb[4] = {0, 0, 0, 0};
+                uint32_t sn[4] = {0, 0, 0, 0};
+                const uint32_t ti = t0 + 4 * (uint32_t)tid;
                 if (ti < ntok) {
-                    const uint2 tk = *(const uint2 *)(tokbuf + ti);  // ti is even; block regions are even-sized
-                    tok_bits(tk.x, b0, n0);
-                    if (ti + 1 < ntok) tok_bits(tk.y, b1, n1);
+                    const uint2 q = *(const uint2 *)(tokbuf + ti);  // ti is a multiple of 4, as are block regions
+                    const uint32_t v[4] = {q.x & 0xffffu, q.x >> 16, q.y & 0xffffu, q.y >> 16};
+                    uint32_t before = ti ? tokbuf[ti - 1] : 0u;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        if (ti + s4 < ntok && !(before & 0x8000u)) {
+                            if (v[s4] & 0x8000u)
+                                match_bits(v[s4], s4 < 3 ? v[(s4 + 1) & 3] : (uint32_t)tokbuf[ti + 4], sb[s4], sn[s4]);
+                            else
+                                lit_bits(v[s4], sb[s4], sn[s4]);
+                        }
+                        before = v[s4];
+                    }
                 }
                 uint32_t total;
-                const uint32_t off = block_scan_excl<EWG / 64>(n0 + n1, &total, misc + M_SCAN);
-                const uint32_t rel = bitpos + off - base_word * 32;
-                stage_or(rel, b0, n0);
-                stage_or(rel + n0, b1, n1);
+                const uint32_t mine = sn[0] + sn[1] + sn[2] + sn[3];
+                const uint32_t off = block_scan_excl<EWG / 64>(mine, &total, misc + M_SCAN);
+                uint32_t rel = bitpos + off - base_word * 32;
+                // neighbours that fit one 64-bit piece together go as one
+                uint64_t acc = 0;
+                uint32_t accn = 0;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    if (!sn[s4]) continue;
+                    if (accn + sn[s4] > 64) {
+                        stage_or(rel, acc, accn);
+                        rel += accn;
+                        acc = 0;
+                        accn = 0;
+                    }
+                    acc |= sb[s4] << accn;
+                    accn += sn[s4];
+                }
+                stage_or(rel, acc, accn);
                 __syncthreads();
                 bitpos += total;
                 const uint32_t full = (bitpos >> 5) - base_word;

@@ -215,7 +215,8 @@ struct zgpu_plan {
     std::vector<uint32_t> first_piece;
     uint64_t *d_in_off = nullptr, *d_slot_off = nullptr, *d_out_off = nullptr;
     uint32_t *d_out_size = nullptr, *d_status = nullptr, *d_crc = nullptr, *d_adler = nullptr;
-    uint32_t *d_tok = nullptr, *d_counter = nullptr;
+    uint16_t *d_tok = nullptr;       // token slots of one round
+    uint32_t *d_counter = nullptr;
     uint64_t *d_tok_off = nullptr;   // per unit: first token within its round's buffer
     uint32_t *d_blk_first = nullptr; // per unit: index of its first block
     uint32_t *d_hist = nullptr, *d_ntok = nullptr;  // per block
@@ -237,10 +238,11 @@ struct zgpu_job {
 
 namespace {
 uint64_t unit_blocks(uint64_t n) { return n ? (n + ZGPU_BLOCK_BYTES - 1) / ZGPU_BLOCK_BYTES : 1; }
-// tokens reserved for a unit: full blocks at their fixed stride, the last one exact (even)
+// token slots (16 bits each) reserved for a unit: full blocks at their fixed stride, the last
+// one exact, rounded so that every region starts on 8 bytes and reads of four slots stay inside
 uint64_t unit_tok_cap(uint64_t n) {
     const uint64_t nb = unit_blocks(n), last = n - (nb - 1) * ZGPU_BLOCK_BYTES;
-    return (nb - 1) * ZGPU_BLOCK_TOK + ((last + 1 + 1) & ~1ull) + 2;
+    return (nb - 1) * ZGPU_BLOCK_TOK + ((last + 1 + 3) & ~3ull) + 4;
 }
 }  // namespace
 
@@ -396,7 +398,7 @@ int zgpu_plan_create(zgpu_plan **out, const uint64_t *in_off, uint32_t n_units, 
     slot[n_pieces] = acc;
     p->tmp_bytes = acc;
     p->out_bound = acc;
-    // Token scratch: 4 bytes per input byte in the worst case.  Pieces are cut into rounds
+    // Token scratch: 2 bytes per input byte in the worst case.  Pieces are cut into rounds
     // whose tokens fit a buffer of at most a third of the free device memory (ZGPU_TOK_BYTES
     // overrides; never less than one maximum-size piece needs).
     std::vector<uint64_t> tok_off(n_pieces);
@@ -407,7 +409,7 @@ int zgpu_plan_create(zgpu_plan **out, const uint64_t *in_off, uint32_t n_units, 
         uint64_t cap_bytes = 8ull << 30;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap_bytes = free_b / 3;
         if (const char *e = getenv("ZGPU_TOK_BYTES")) cap_bytes = strtoull(e, nullptr, 10);
-        const uint64_t cap_tokens = cap_bytes / 4;
+        const uint64_t cap_tokens = cap_bytes / 2;
         uint64_t used = 0;
         uint32_t first = 0;
         for (uint32_t i = 0; i < n_pieces; ++i) {
@@ -451,7 +453,7 @@ int zgpu_plan_create(zgpu_plan **out, const uint64_t *in_off, uint32_t n_units, 
     PCHK(hipMalloc(&p->d_counter, (p->rounds.size() * 2 + 2) * 4));
     PCHK(hipMalloc(&p->d_out_tmp, p->tmp_bytes + 64));
     if (ctype != ZGPU_NONE) {
-        PCHK(hipMalloc(&p->d_tok, (size_t)tok_buf_tokens * 4 + 64));
+        PCHK(hipMalloc(&p->d_tok, (size_t)tok_buf_tokens * 2 + 64));
         PCHK(hipMalloc(&p->d_tok_off, (size_t)n_pieces * 8));
         PCHK(hipMalloc(&p->d_blk_first, (size_t)n_pieces * 4));
         PCHK(hipMalloc(&p->d_hist, (size_t)n_blocks * 320 * 4));

@@ -2,11 +2,13 @@
 #pragma once
 #include <stdint.h>
 
-// one DEFLATE block per this many input bytes; a block yields at most that many
-// tokens plus end-of-block, and block b of a unit starts ZGPU_BLOCK_TOK * b
-// tokens into the unit's token region (even, so two tokens load as one 8 bytes)
+// One DEFLATE block per this many input bytes.  The token stream between the two
+// kernels is made of 16-bit slots: a literal or end-of-block (256) takes one, a match
+// two (0x8000 | length - 3, then distance - 1), so a block yields at most one slot per
+// input byte plus end-of-block; block b of a unit starts ZGPU_BLOCK_TOK * b slots into
+// the unit's region (a multiple of 4, so four slots load as one 8 bytes)
 #define ZGPU_BLOCK_BYTES 65536u
-#define ZGPU_BLOCK_TOK (ZGPU_BLOCK_BYTES + 2u)
+#define ZGPU_BLOCK_TOK (ZGPU_BLOCK_BYTES + 4u)
 // workgroups of the DEFLATE kernel that fit one CU (LDS-bound)
 #define ZGPU_DEFLATE_WG_PER_CU 1
 // workgroups of the emit kernel queued per CU (small LDS footprint, latency bound)
