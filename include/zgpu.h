@@ -13,6 +13,12 @@
  * "device" pointers are HIP device pointers on the current HIP device.
  * There is no CPU fallback: without a usable GPU the calls fail with
  * ZGPU_E_NODEVICE.
+ *
+ * Threads: calls on different plans or jobs may run side by side, on one device
+ * or several.  One plan serves one run at a time (run, fetch and the timing
+ * queries of a plan are not to overlap), and the engine knobs (zgpu_set_*) and
+ * zgpu_init / zgpu_shutdown are process-wide: set them while no call is in
+ * flight.  zgpu_last_hip_error is per thread.
  */
 #ifndef ZGPU_H
 #define ZGPU_H
