@@ -193,6 +193,37 @@ def test_lazy_roundtrip_and_gain(z):
     assert s8 <= s0 and s32 <= s8 * 1.001
 
 
+def test_calls_from_several_threads(z):
+    # host-buffer calls and checksums side by side from four threads (ctypes drops the GIL):
+    # every thread gets what a lone call gets
+    import threading
+    jobs = []
+    for t in range(4):
+        units = [zo.gen({"gen": ("text", "rndseq", "rnd", "runs")[(t + i) % 4], "n": 20_000 + 7919 * i, "seed": 10 * t + i})
+                 for i in range(12)]
+        jobs.append((units, z.deflate_batch(units, 2, 0, want_crc=True, want_adler=True),
+                     [z.checksum(u) for u in units[:3]]))
+    results, errors = [None] * 4, []
+
+    def work(t):
+        try:
+            for _ in range(5):
+                units, want, want_ck = jobs[t]
+                got = z.deflate_batch(units, 2, 0, want_crc=True, want_adler=True)
+                ck = [z.checksum(u) for u in units[:3]]
+                if got != want or ck != want_ck:
+                    errors.append(t)
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(120)
+    assert not errors and not any(th.is_alive() for th in threads)
+
+
 def test_host_batch_in_two_steps(z):
     import ctypes as C
     N = z._native
