@@ -85,10 +85,17 @@ def main():
                 "lds_bank_conflict_frac": round(q2["SQ_LDS_BANK_CONFLICT"] / cu_cycles, 4),
                 "lds_wave_insts_per_input_byte": round(q1["SQ_INSTS_LDS"] / nbytes, 3),
                 "valu_wave_insts_per_input_byte": round(q1["SQ_INSTS_VALU"] / nbytes, 3),
-                "valu_busy_frac": round(4.0 * q1["SQ_INSTS_VALU"] / q1["SQ_WAVE_CYCLES"], 4),
+                "valu_issue_frac_of_peak": round(2.0 * q1["SQ_INSTS_VALU"] / q1["SQ_WAVE_CYCLES"], 4),
+                "waves_in_valu_per_simd": round(4.0 * q1["SQ_ACTIVE_INST_VALU"] / q1["SQ_WAVE_CYCLES"], 3),
+                "salu_wave_insts_per_input_byte": round(q1["SQ_INSTS_SALU"] / nbytes, 3),
+                "wave_cycles_active_frac": round(q2["SQ_ACTIVE_INST_ANY"] / q1["SQ_WAVE_CYCLES"], 4),
+                "wave_cycles_waitcnt_frac": round(q2["SQ_WAIT_ANY"] / q1["SQ_WAVE_CYCLES"], 4),
+                "wave_cycles_wait_issue_frac": round(q2["SQ_WAIT_INST_ANY"] / q1["SQ_WAVE_CYCLES"], 4),
                 "note": "SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT over CU-cycles (SQ_BUSY_CYCLES / 32 SEs x 256 CUs); "
-                        "VALU: a wave instruction holds its SIMD for 4 cycles; SQ_WAVE_CYCLES counts 4-cycle units summed "
-                        "over the 4 waves a SIMD holds, so SIMD-cycles = SQ_WAVE_CYCLES and busy = 4 x SQ_INSTS_VALU / SQ_WAVE_CYCLES",
+                        "VALU: a SIMD-32 issues a wave64 instruction over 2 cycles (one wave alone sustains one per 4); "
+                        "SQ_WAVE_CYCLES counts 4-cycle units summed over the 4 waves a SIMD holds, so it equals the "
+                        "SIMD-cycles and the share of the SIMD's peak issue rate is 2 x SQ_INSTS_VALU / SQ_WAVE_CYCLES; "
+                        "the wave_cycles_* shares split the waves' own time (SQ_ACTIVE_INST_ANY, SQ_WAIT_ANY, SQ_WAIT_INST_ANY)",
             }
         except KeyError:
             pass
