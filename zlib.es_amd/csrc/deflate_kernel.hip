@@ -981,7 +981,10 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     }
                 ++npend;
                 lds_publish(&slot_done[k & (NSLOT - 1)], k + 1);
-                try_advance();
+                // Only the wave whose item the frontier stands at has something to advance.  A
+                // frontier on its way here either sees the stamp, or publishes M_PARSE = k after
+                // this look and then looks at the stamp again (the check after its unlock).
+                if (lds_ld(&misc[M_PARSE]) == k) try_advance();
             }
             while (npend > 0) emit_oldest(blk_end);
             // also a wave that got no item in this block must not hold the frontier back
