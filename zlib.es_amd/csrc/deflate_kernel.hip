@@ -709,11 +709,11 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 }
                 return (uint32_t)lane + adv;
             };
-            auto resolved = [&](uint32_t k0) -> bool {
-                return (int32_t)(lds_ld(&misc[M_PARSE]) - k0) > 0;
-            };
             // cur: the item the wave is working on (the block's end when it has taken its last)
-            auto emit_oldest = [&](uint32_t cur) {
+            // must: wait for the frontier if it has not passed the item yet; else leave the item
+            // waiting and return false.  One LDS round trip tells both whether it has passed
+            // and, if so, where the item's tokens start.
+            auto emit_oldest = [&](uint32_t cur, bool must) -> bool {
                 // ---- tokens of item q_k[0]: lane l <-> local index l ----
                 // The parse path through the item is walked on scalar registers: literal runs
                 // are skipped with a find-first-set over the ballot of match positions, a
@@ -723,15 +723,24 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 const uint32_t p0 = k0 << 6, sl = k0 & (NSLOT_E - 1);
                 const uint32_t seg_end = (n - p0) < 64u ? (n - p0) : 64u;
                 PH_START();
-                while (!resolved(k0)) {
+                // the frontier writes an item's slot before it publishes M_PARSE, and the LDS
+                // serves this wave's reads in order: slot values read after a M_PARSE that shows
+                // the item passed are the item's
+                uint32_t fr = lds_ld(&misc[M_PARSE]);
+                uint32_t s_ent = lds_ld(&slot_entry[sl]), s_tok = lds_ld(&slot_tokb[sl]);
+                while ((int32_t)(fr - k0) <= 0) {
+                    if (!must) return false;
                     try_advance();
                     __builtin_amdgcn_s_sleep(1);
+                    fr = lds_ld(&misc[M_PARSE]);
+                    s_ent = lds_ld(&slot_entry[sl]);
+                    s_tok = lds_ld(&slot_tokb[sl]);
                 }
                 asm volatile("" ::: "memory");
                 PH_END(15);
                 // local index of the first token (>= seg_end: a match from before covers the item)
-                const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_entry[sl]) - p0;
-                const uint32_t tokbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot_tokb[sl]);
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ent) - p0;
+                const uint32_t tokbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tok);
                 // both are in registers: this wave's oldest item with tokens to come is the next
                 // one.  A frontier held at this item's bound either shows in M_PARSE now, or
                 // its wave has yet to publish M_PARSE and looks at the bound again after that.
@@ -791,6 +800,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 --npend;
                 PH_END(7);
                 if (frontier_held) try_advance();
+                return true;
             };
             for (;;) {
                 uint32_t k = 0;
@@ -807,7 +817,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 const uint32_t p = p0 + (uint32_t)lane;
                 // An unparsed item more than LAG items back must be parsed first, or the
                 // waves that wait for it below could never be released.
-                while (npend > 0 && k > q_k[0] + LAG) emit_oldest(k);
+                while (npend > 0 && k > q_k[0] + LAG) emit_oldest(k, true);
                 // bound the spread of in-flight items: everything more than LAG items back is
                 // parsed, so no wave still reads ring bytes or chain slots that get recycled
                 if (k > LAG) lds_wait_ge(&misc[M_PARSE], k - LAG);
@@ -972,7 +982,8 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 PH_END(14);
                 // tokens of items the frontier has passed leave before this item is stamped:
                 // until then the frontier cannot run far enough to recycle their slots
-                while (npend > 0 && (npend == PEND || resolved(q_k[0]))) emit_oldest(k);
+                while (npend > 0 && emit_oldest(k, npend == PEND)) {
+                }
 #pragma unroll
                 for (int i = 0; i < PEND; ++i)
                     if (i == npend) {
@@ -986,7 +997,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 // this look and then looks at the stamp again (the check after its unlock).
                 if (lds_ld(&misc[M_PARSE]) == k) try_advance();
             }
-            while (npend > 0) emit_oldest(blk_end);
+            while (npend > 0) emit_oldest(blk_end, true);
             // also a wave that got no item in this block must not hold the frontier back
             lds_publish(&misc[M_OLDEST + (tid >> 6)], blk_end);
             try_advance();
