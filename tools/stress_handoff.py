@@ -4,7 +4,7 @@ compressed over and over with search settings that make the search itself short 
 waves spend their time in the linking and parsing hand-offs), and every output stream is
 checked on the device each time.
 
-usage: stress_handoff.py [REPS] [UNITS]"""
+usage: stress_handoff.py [REPS] [UNITS] [small]     (small: units of 0 .. 2000 bytes)"""
 import os
 import sys
 import time
@@ -21,6 +21,7 @@ import zlib_es_amd as z  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 nu = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+small = len(sys.argv) > 3 and sys.argv[3] == "small"
 dev = torch.device("cuda:0")
 torch.cuda.init()
 data = bench.gen_units(nu, 65536, 5, dev)
@@ -30,6 +31,9 @@ cuts = [0]
 total = nu * 65536
 while cuts[-1] < total:
     r = rng.random()
+    if small:
+        cuts.append(min(total, cuts[-1] + int(rng.integers(0, 2000))))
+        continue
     n = int(rng.integers(1, 3000)) if r < 0.2 else int(rng.integers(3000, 140000)) if r < 0.9 else int(rng.integers(140000, 400000))
     cuts.append(min(total, cuts[-1] + n))
 in_off = np.array(cuts, dtype=np.uint64)
