@@ -260,6 +260,20 @@ __device__ inline void lds_publish(uint32_t *word, uint32_t value) {
 
 using zgpu_sort::wave_sort64;  // one key per lane, ascending by lane, in registers
 
+// The neighbouring lane's value by a DPP wave shift (one VALU instruction, no LDS crossbar trip);
+// every lane of the wave must be active.  from_below: lane i gets lane i - 1's value, lane 0 gets
+// `edge`; from_above: lane i gets lane i + 1's, lane 63 gets `edge`.
+__device__ inline uint32_t from_below(uint32_t v, uint32_t edge) {
+    uint32_t r = edge;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v));
+    return r;
+}
+__device__ inline uint32_t from_above(uint32_t v, uint32_t edge) {
+    uint32_t r = edge;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v));
+    return r;
+}
+
 // RFC 1951 length symbol for l = len-3 (0..255): symbol, extra bit count, extra value
 __device__ inline void len_sym(uint32_t l, uint32_t &sym, uint32_t &eb, uint32_t &ev) {
     if (l < 8) {
@@ -691,7 +705,8 @@ __device__ __forceinline__ void search_units(const Params &P) {
             // Up to PEND searched items wait per wave until the frontier has passed them
             // (slot 0 is the oldest); then their tokens are emitted.
             int npend = 0;
-            uint32_t q_k[PEND], q_ld[PEND];  // item, best length << 16 | best distance per lane
+            // item; per lane: the position's byte << 24 | best length << 15 | best distance - 1
+            uint32_t q_k[PEND], q_ld[PEND];
             // kind / successor of every local index of an item (0 literal, 1 match here,
             // 2 literal + match at +1); no look-ahead across the item boundary
             auto successor = [&](uint32_t best_len, uint32_t l1, uint32_t &kind) -> uint32_t {
@@ -746,10 +761,9 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 // its wave has yet to publish M_PARSE and looks at the bound again after that.
                 lds_publish(&misc[M_OLDEST + (tid >> 6)], npend > 1 ? q_k[1] : cur);
                 const bool frontier_held = lds_ld(&misc[M_PARSE]) == k0 + NSLOT_E;
-                uint32_t ldn = __shfl_down(ld, 1, 64);  // the next position's match (lazy tokens)
-                if (lane == 63) ldn = 0;
+                const uint32_t ldn = from_above(ld, 0u);  // the next position's match (lazy tokens)
                 uint32_t kind;
-                const uint32_t J = successor(ld >> 16, ldn >> 16, kind);
+                const uint32_t J = successor((ld >> 15) & 0x1ffu, (ldn >> 15) & 0x1ffu, kind);
                 const unsigned long long valid = seg_end == 64u ? ~0ull : ((1ull << seg_end) - 1ull);
                 const unsigned long long M = __ballot(kind != 0) & valid;
                 unsigned long long path = 0;
@@ -776,13 +790,13 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         __builtin_amdgcn_mbcnt_hi((uint32_t)(two >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)two, 0u));
                     uint16_t *dst = tokbuf + tokbase + idx;
                     if (kind != 1) {
-                        const uint32_t b = ring[(p0 + (uint32_t)lane) & (RING - 1)];
+                        const uint32_t b = ld >> 24;
                         *dst++ = (uint16_t)b;
                         atomicAdd(&fl[b], 1u);
                     }
                     if (kind != 0) {
                         const uint32_t t = kind == 1 ? ld : ldn;
-                        const uint32_t tl = t >> 16, td = t & 0xffffu;
+                        const uint32_t tl = (t >> 15) & 0x1ffu, td = (t & 0x7fffu) + 1;
                         dst[0] = (uint16_t)(0x8000u | (tl - 3));
                         dst[1] = (uint16_t)(td - 1);
                         uint32_t sym, eb, ev;
@@ -843,7 +857,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 if (p + 3 <= n) key = (hash3(own.x) << 6) | (uint32_t)lane;
                 key = wave_sort64(key);
                 {
-                    const uint32_t kp = __shfl_up(key, 1, 64), kn = __shfl_down(key, 1, 64);
+                    const uint32_t kp = from_below(key, 0u), kn = from_above(key, 0xffffffffu);
                     const uint32_t h = key >> 6;
                     const bool live = key != 0xffffffffu;
                     const bool first = lane == 0 || (kp >> 6) != h;
@@ -926,13 +940,14 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         unsigned long long todo = __ballot(blen >= SHARE_MIN);
                         for (int it = 0; it < share_iters; ++it) {
                             if (!todo) break;
-                            const uint32_t d = (uint32_t)__shfl((int)offer, __builtin_ctzll(todo), 64);
+                            const uint32_t d = rl(offer, (uint32_t)__builtin_ctzll(todo));  // a uniform lane: v_readlane, no LDS
                             uint32_t run = 0;
                             bool open = true;
                             for (uint32_t w = 0; w < 6; ++w) {
                                 const uint32_t q = p0 + (w << 6) + (uint32_t)lane;
-                                const bool eq = q < n && q >= d &&
-                                                ring[q & (RING - 1)] == ring[(q - d) & (RING - 1)];
+                                // window 0 is the item itself: its bytes are in registers
+                                const uint32_t mine = w == 0 ? (own.x & 0xffu) : (uint32_t)ring[q & (RING - 1)];
+                                const bool eq = q < n && q >= d && mine == ring[(q - d) & (RING - 1)];
                                 const unsigned long long m = __ballot(eq);
                                 if (w == 0) {
                                     // zeros shifted in from the top read as mismatches after the inversion
@@ -962,18 +977,19 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     // ---- exit index and token count of every local index (six doubling steps) ----
                     const uint32_t seg_end = (n - p0) < 64u ? (n - p0) : 64u;
                     uint32_t kind;
-                    uint32_t l1 = __shfl_down(best_len, 1, 64);
-                    if (lane == 63) l1 = 0;
+                    const uint32_t l1 = from_above(best_len, 0u);
                     uint32_t J = successor(best_len, l1, kind);
                     if ((uint32_t)lane >= seg_end) J = (uint32_t)lane;  // past the end: stay put
                     uint32_t Cn = (uint32_t)lane < seg_end ? 1u + kind : 0u;  // slots: literal 1, match 2, literal + match 3
 #pragma unroll
                     for (int r = 0; r < 6; ++r) {
-                        const int idx = (int)(J & 63u);
-                        const uint32_t tj = __shfl(J, idx, 64), tc = __shfl(Cn, idx, 64);
+                        // every index already leaves the item (long matches): nothing left to double
+                        if (!__ballot(J < seg_end)) break;
+                        // exit and count travel together: one permute per doubling step
+                        const uint32_t t = (uint32_t)__shfl((int)(J | Cn << 16), (int)(J & 63u), 64);
                         const bool inb = J < seg_end;
-                        Cn += inb ? tc : 0u;
-                        J = inb ? tj : J;
+                        Cn += inb ? t >> 16 : 0u;
+                        J = inb ? (t & 0xffffu) : J;
                     }
                     const uint32_t sl = k & (NSLOT - 1);
                     exit_tab[sl * 64 + lane] = (uint16_t)J;
@@ -988,7 +1004,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 for (int i = 0; i < PEND; ++i)
                     if (i == npend) {
                         q_k[i] = k;
-                        q_ld[i] = best_len << 16 | best_dist;
+                        q_ld[i] = (own.x & 0xffu) << 24 | best_len << 15 | ((best_dist - 1) & 0x7fffu);
                     }
                 ++npend;
                 lds_publish(&slot_done[k & (NSLOT - 1)], k + 1);

@@ -4,7 +4,8 @@
 // A compare-exchange with the lane at distance j is three VALU instructions where
 // the partner is reachable by a single DPP pattern (j = 1, 2: quad_perm; j = 8:
 // row_ror:8): a DPP min, a DPP max and a select.  j = 4 takes two banked row
-// shifts, j = 16 / 32 the gfx950 row / half-wave swaps.  Which lanes keep the
+// shifts, j = 16 / 32 the gfx950 row / half-wave swaps (v_permlane16_swap,
+// v_permlane32_swap) and a select: no step goes through the LDS crossbar.  Which lanes keep the
 // smaller key at a step is a compile-time 64-bit mask held in scalar registers.
 #ifndef ZGPU_WAVE_SORT_H
 #define ZGPU_WAVE_SORT_H
@@ -64,7 +65,19 @@ __device__ inline uint32_t cx(uint32_t key) {
         key = cx_other(key, o, mask);
     } else {
         static_assert(J == 16 || J == 32, "distance");
-        key = cx_other(key, (uint32_t)__shfl_xor((int)key, (int)J, 64), mask);
+        // gfx950 row / half-wave swaps of the key with itself leave the even rows (lower half)
+        // in every row (half) of .x and the odd rows (upper half) in .y: a lane's partner is in
+        // .y if the lane sits in an even row (lower half), else in .x
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        constexpr uint64_t upper = J == 16 ? 0xffff0000ffff0000ull : 0xffffffff00000000ull;
+        v2u s;
+        if constexpr (J == 16)
+            s = __builtin_amdgcn_permlane16_swap(key, key, false, false);
+        else
+            s = __builtin_amdgcn_permlane32_swap(key, key, false, false);
+        uint32_t other;
+        asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(other) : "v"(s.y), "v"(s.x), "s"(upper));
+        key = cx_other(key, other, mask);
     }
     return key;
 }
