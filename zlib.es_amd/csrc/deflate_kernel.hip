@@ -941,25 +941,43 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         for (int it = 0; it < share_iters; ++it) {
                             if (!todo) break;
                             const uint32_t d = rl(offer, (uint32_t)__builtin_ctzll(todo));  // a uniform lane: v_readlane, no LDS
-                            uint32_t run = 0;
-                            bool open = true;
-                            for (uint32_t w = 0; w < 6; ++w) {
-                                const uint32_t q = p0 + (w << 6) + (uint32_t)lane;
-                                // window 0 is the item itself: its bytes are in registers
-                                const uint32_t mine = w == 0 ? (own.x & 0xffu) : (uint32_t)ring[q & (RING - 1)];
-                                const bool eq = q < n && q >= d && mine == ring[(q - d) & (RING - 1)];
-                                const unsigned long long m = __ballot(eq);
-                                if (w == 0) {
-                                    // zeros shifted in from the top read as mismatches after the inversion
-                                    const unsigned long long inv = ~(m >> lane);
-                                    run = inv ? (uint32_t)__builtin_ctzll(inv) : 64u;
-                                    open = run == 64u - (uint32_t)lane;
-                                } else if (open) {
-                                    const uint32_t r2 = ~m ? (uint32_t)__builtin_ctzll(~m) : 64u;
-                                    run += r2;
-                                    open = r2 == 64u;
+                            // the item's own 64 positions: one byte compare per lane (the item's bytes
+                            // are in registers), a ballot, count-trailing-ones of the shifted mask
+                            uint32_t run;
+                            bool open;
+                            {
+                                const bool eq = p < n && p >= d && (own.x & 0xffu) == ring[(p - d) & (RING - 1)];
+                                // zeros shifted in from the top read as mismatches after the inversion
+                                const unsigned long long inv = ~(__ballot(eq) >> lane);
+                                run = inv ? (uint32_t)__builtin_ctzll(inv) : 64u;
+                                open = run == 64u - (uint32_t)lane;
+                            }
+                            // Beyond the item every match that is still open continues the same way:
+                            // one number, how far the data at p0 + 64 goes on matching at this
+                            // distance.  Four positions per lane and step: an aligned dword against
+                            // a dword shifted into place, first differing byte by find-first-set,
+                            // first differing lane by ballot.
+                            if (__ballot(open)) {
+                                uint32_t ext = 0;
+                                for (uint32_t st = 0; st < 2; ++st) {
+                                    const uint32_t q4 = p0 + 64u + (st << 8) + ((uint32_t)lane << 2);
+                                    const uint32_t a = *(const uint32_t *)(ring + (q4 & (RING - 1)));
+                                    const uint32_t s4 = q4 - d;
+                                    const uint32_t b0 = *(const uint32_t *)(ring + (s4 & (RING - 1) & ~3u));
+                                    const uint32_t b1 = *(const uint32_t *)(ring + ((s4 + 4u) & (RING - 1) & ~3u));
+                                    uint32_t x = a ^ __builtin_amdgcn_alignbyte(b1, b0, s4 & 3u);
+                                    // positions past the unit's end differ by decree
+                                    const uint32_t left = q4 < n ? n - q4 : 0u;
+                                    if (left < 4u) x |= left ? 0xffffffffu << (left << 3) : 0xffffffffu;
+                                    const unsigned long long mm = __ballot(x != 0u);
+                                    if (mm) {
+                                        const uint32_t fl_ = (uint32_t)__builtin_ctzll(mm);
+                                        ext += (fl_ << 2) + (rl(ffbl(x), fl_) >> 3);
+                                        break;
+                                    }
+                                    ext += 256u;
                                 }
-                                if (!__ballot(open && run < 258u)) break;
+                                if (open) run += ext;
                             }
                             if (run > maxlen) run = maxlen;
                             if (run >= 3 && d <= limit && (run > blen || (run == blen && d < best_dist))) {
