@@ -135,7 +135,7 @@ def main():
     import zlib_es_amd as z
     N = z._native
     if args.chain or args.nice != 32:
-        z.set_search(args.chain or 8, args.nice)
+        z.set_search(args.chain or z._native.DEFAULT_MAX_CHAIN, args.nice)
 
     def barrier():
         torch.cuda.synchronize()

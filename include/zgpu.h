@@ -78,7 +78,7 @@ const char *zgpu_strerror(int code);
 int zgpu_last_hip_error(void);
 /* Engine knobs (the reference searches every earlier occurrence,
  * src/rawdeflate.js:370-395; these bound the search).  max_chain: candidates
- * examined per position (1..32768, default 8).  nice_length: a candidate at
+ * examined per position (1..32768, default 6).  nice_length: a candidate at
  * least this long ends the walk (3..258, default 32, the length up to which
  * candidates are compared one by one; matches are still extended to their full
  * length).  With nice_length > 32 every candidate is compared to its full

@@ -68,7 +68,7 @@ def test_argument_errors_need_no_gpu():
     assert L.zgpu_plan_create(ctypes.byref(plan), ok.ctypes.data, 0, 2, 0, 1) == -2           # no units
     back = np.array([10, 0], dtype=np.uint64)
     assert L.zgpu_plan_create(ctypes.byref(plan), back.ctypes.data, 1, 2, 0, 1) == -2         # offsets go backwards
-    assert L.zgpu_set_search(0, 32) == -2 and L.zgpu_set_search(8, 259) == -2 and L.zgpu_set_search(8, 32) == 0
+    assert L.zgpu_set_search(0, 32) == -2 and L.zgpu_set_search(8, 259) == -2 and L.zgpu_set_search(N.DEFAULT_MAX_CHAIN, N.DEFAULT_NICE_LENGTH) == 0
     assert L.zgpu_set_split(4096) == -2 and L.zgpu_set_split(1 << 20) == 0
     assert L.zgpu_set_min_lazy(-1) == -2 and L.zgpu_set_min_lazy(258) == 0
     assert b"compression type" in ctypes.cast(L.zgpu_strerror(-2), ctypes.c_char_p).value

@@ -76,7 +76,7 @@ def test_random_batches(seed):
                 assert zo.inflate_raw(stream, flat.size) == flat.tobytes()
             assert all(len(o) <= z.deflate_bound(len(d)) for o, d in zip(outs, origs))
     finally:
-        z.set_search(8, 32)
+        z.set_search()
 
 
 def _skewed_unit(rng):
@@ -142,4 +142,4 @@ def test_skewed_symbol_statistics(seed):
             for i in range(0, len(outs), 40):  # and a sample through the CPU decoder
                 assert zo.inflate_raw(outs[i], datas[i].size) == datas[i].tobytes()
     finally:
-        z.set_search(8, 32)
+        z.set_search()

@@ -124,7 +124,7 @@ def test_exhaustive_search_meets_the_bar_case_by_case(z, golden, ctype):
     try:
         sizes = _roundtrip(z, datas, ctype)
     finally:
-        z.set_search(8, 32)
+        z.set_search()
     for c, s in zip(cases, sizes):
         assert s <= RATIO_BAR * c["raw"][str(ctype)]["len"], (c["spec"], s)
 

@@ -44,8 +44,8 @@ for rep in range(reps):
     N = z._native
     chain, nice, ctype, lazy, flags = [
         (1, 8, 1, 0, N.F_FINAL_EACH), (1, 3, 2, 0, N.F_FINAL_EACH), (2, 32, 2, 0, N.F_FINAL_EACH),
-        (8, 32, 2, 0, N.F_FINAL_EACH), (8, 258, 2, 0, N.F_FINAL_EACH), (3, 32, 1, 8, N.F_FINAL_EACH),
-        (8, 32, 2, 0, N.F_SYNC_ALIGN | N.F_FINAL_LAST | N.F_PRIME_WINDOW), (1, 258, 2, 4, N.F_SYNC_ALIGN | N.F_FINAL_LAST | N.F_PRIME_WINDOW),
+        (6, 32, 2, 0, N.F_FINAL_EACH), (8, 258, 2, 0, N.F_FINAL_EACH), (3, 32, 1, 8, N.F_FINAL_EACH),
+        (6, 32, 2, 0, N.F_SYNC_ALIGN | N.F_FINAL_LAST | N.F_PRIME_WINDOW), (1, 258, 2, 4, N.F_SYNC_ALIGN | N.F_FINAL_LAST | N.F_PRIME_WINDOW),
     ][rep % 8]
     z.set_search(chain, nice)
     plan = z.Plan(in_off, ctype, lazy, flags)
@@ -61,6 +61,6 @@ for rep in range(reps):
             rep, chain, nice, ctype, lazy, flags, in_off.size - 1, [(u, int(in_off[u + 1] - in_off[u])) for u in bad[:5]],
             time.time() - t0), flush=True)
     del plan, out
-z.set_search(8, 32)
+z.set_search()
 print("failures:", bad_total)
 sys.exit(1 if bad_total else 0)

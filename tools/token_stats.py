@@ -36,4 +36,4 @@ for spec in specs:
             c = toks(o, d.size)
             print("   nice %3d chain %3d: bytes %6d (%.3f) (literals, matches) %s" % (nice, chain, len(o), len(o) / len(ref), c))
 z._native.set_min_lazy(258)
-z.set_search(8, 32)
+z.set_search()

@@ -120,7 +120,12 @@ def deflate_bound(n):
     return int(lib().zgpu_deflate_bound(n))
 
 
-def set_search(max_chain, nice_length=32):
+# the library's own search settings (zgpu_set_search documents them)
+DEFAULT_MAX_CHAIN, DEFAULT_NICE_LENGTH = 6, 32
+
+
+def set_search(max_chain=DEFAULT_MAX_CHAIN, nice_length=DEFAULT_NICE_LENGTH):
+    """Engine-wide search settings; without arguments back to the library's defaults."""
     _check(lib().zgpu_set_search(max_chain, nice_length), "zgpu_set_search")
 
 
