@@ -84,7 +84,7 @@ int zgpu_last_hip_error(void);
  * length).  With nice_length > 32 every candidate is compared to its full
  * length and the longest wins (the nearest among equals): (32768, 258) is the
  * reference's exhaustive search, two orders of magnitude slower than the
- * default; (8, 258) costs about 40 % of the speed and makes highly repetitive
+ * default; (8, 258) costs about 45 % of the speed and makes highly repetitive
  * input up to 15 % smaller. */
 int zgpu_set_search(int max_chain, int nice_length);
 /* In a batch of fewer than 16 units per compute unit, a unit longer than two
