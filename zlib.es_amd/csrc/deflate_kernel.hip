@@ -43,7 +43,7 @@ constexpr int HBITS = 13;           // hash-head table entries = 1 << HBITS
 constexpr uint32_t RING = 65536;    // LDS input ring (bytes)
 constexpr uint32_t RING_PAD = 272;  // mirror of ring[0..272) after the end
 constexpr uint32_t WMASK = 0x7fff;  // chain slots (32 Ki positions)
-constexpr int PEND = 3;             // searched items a wave may hold before it must parse the oldest
+constexpr int PEND = 2;             // searched items a wave may hold before it must parse the oldest
 constexpr uint32_t LAG = 48;        // an item starts only when all items more than LAG back are parsed
 constexpr uint32_t MAXDIST = 32768 - 64 * LAG - 128;  // window minus the span of in-flight items
 constexpr uint32_t BLK_ITEMS = 1024;  // one DEFLATE block per 64 KiB of input
