@@ -78,13 +78,13 @@ const char *zgpu_strerror(int code);
 int zgpu_last_hip_error(void);
 /* Engine knobs (the reference searches every earlier occurrence,
  * src/rawdeflate.js:370-395; these bound the search).  max_chain: candidates
- * examined per position (1..32768, default 6).  nice_length: a candidate at
+ * examined per position (1..32768, default 8).  nice_length: a candidate at
  * least this long ends the walk (3..258, default 32, the length up to which
  * candidates are compared one by one; matches are still extended to their full
  * length).  With nice_length > 32 every candidate is compared to its full
  * length and the longest wins (the nearest among equals): (32768, 258) is the
  * reference's exhaustive search, two orders of magnitude slower than the
- * default; (8, 258) costs about 45 % of the speed and makes highly repetitive
+ * default; (8, 258) costs about 40 % of the speed and makes highly repetitive
  * input up to 15 % smaller. */
 int zgpu_set_search(int max_chain, int nice_length);
 /* In a batch of fewer than 16 units per compute unit, a unit longer than two

@@ -14,7 +14,7 @@ import zlib_es_amd as z  # noqa: E402
 golden = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
 cases = [c for c in golden["cases"] if c["n"] >= 16384]
 datas = [zo.gen(c["spec"]) for c in cases]
-chains = [int(x) for x in os.environ.get("CHAINS", "6,16,32,128").split(",")]
+chains = [int(x) for x in os.environ.get("CHAINS", "8,16,32,128").split(",")]
 LAZY = int(os.environ.get("LAZY", "0"))
 NICE = int(os.environ.get("NICE", "32"))
 for ct in (1, 2):

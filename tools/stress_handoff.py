@@ -44,8 +44,8 @@ for rep in range(reps):
     N = z._native
     chain, nice, ctype, lazy, flags = [
         (1, 8, 1, 0, N.F_FINAL_EACH), (1, 3, 2, 0, N.F_FINAL_EACH), (2, 32, 2, 0, N.F_FINAL_EACH),
-        (6, 32, 2, 0, N.F_FINAL_EACH), (8, 258, 2, 0, N.F_FINAL_EACH), (3, 32, 1, 8, N.F_FINAL_EACH),
-        (6, 32, 2, 0, N.F_SYNC_ALIGN | N.F_FINAL_LAST | N.F_PRIME_WINDOW), (1, 258, 2, 4, N.F_SYNC_ALIGN | N.F_FINAL_LAST | N.F_PRIME_WINDOW),
+        (8, 32, 2, 0, N.F_FINAL_EACH), (8, 258, 2, 0, N.F_FINAL_EACH), (3, 32, 1, 8, N.F_FINAL_EACH),
+        (8, 32, 2, 0, N.F_SYNC_ALIGN | N.F_FINAL_LAST | N.F_PRIME_WINDOW), (1, 258, 2, 4, N.F_SYNC_ALIGN | N.F_FINAL_LAST | N.F_PRIME_WINDOW),
     ][rep % 8]
     z.set_search(chain, nice)
     plan = z.Plan(in_off, ctype, lazy, flags)

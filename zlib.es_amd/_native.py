@@ -121,7 +121,7 @@ def deflate_bound(n):
 
 
 # the library's own search settings (zgpu_set_search documents them)
-DEFAULT_MAX_CHAIN, DEFAULT_NICE_LENGTH = 6, 32
+DEFAULT_MAX_CHAIN, DEFAULT_NICE_LENGTH = 8, 32
 
 
 def set_search(max_chain=DEFAULT_MAX_CHAIN, nice_length=DEFAULT_NICE_LENGTH):

@@ -18,7 +18,7 @@
 namespace {
 
 thread_local int g_last_hip = 0;
-int g_max_chain = 6;
+int g_max_chain = 8;
 int g_nice = 32;
 uint64_t g_split_bytes = 1ull << 20;  // units longer than twice this are cut into pieces of at most this size
 int g_min_lazy = 258;  // the parse always looks one position ahead unless told otherwise
