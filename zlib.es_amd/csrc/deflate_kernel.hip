@@ -1,22 +1,34 @@
-// DEFLATE encoder kernel for gfx950 (MI355X): one 1024-thread workgroup per
-// unit (block / zip entry / stream chunk), persistent over a unit queue.
+// DEFLATE encoder kernels for gfx950 (MI355X).
 //
-// Replaces, per unit, the reference's RawDeflate.compress() pipeline
-// (src/rawdeflate.js:102-124): lz77 + searchLongestMatch_ (:283-395), the
-// Huffman code construction (:474-605), the block header (:176-236) and the
-// bit emission (:243-277, src/bitstream.js:42-95).
+// Replace, per unit (block / zip entry / stream chunk), the reference's
+// RawDeflate.compress() pipeline (src/rawdeflate.js:102-124): lz77 +
+// searchLongestMatch_ (:283-395), the Huffman code construction (:474-605),
+// the block header (:176-236) and the bit emission (:243-277,
+// src/bitstream.js:42-95).
 //
-// Per unit the workgroup streams through the input in 1 KiB chunks:
-//   load    input -> 64 KiB LDS ring (the 32 KiB window stays resident)
-//   insert  hash every position, sort (hash,pos) pairs, link hash chains
-//   search  one lane per position walks its chain (bounded depth), scoring
-//           candidates with 4-byte xor/ctz compares against the LDS ring
-//   parse   greedy / one-step-lazy successor per position, reachable set by
-//           pointer doubling, tokens compacted with a workgroup prefix sum,
-//           symbol histograms by LDS atomics
-// and every 64 chunks (or at the end) closes a DEFLATE block:
-//   codes   length-limited Huffman code lengths + canonical codes
-//   emit    per-token bit strings, prefix sum of bit lengths, LDS-staged
+// Search kernel (zgpu_deflate_kernel, zgpu_deflate_thorough_kernel): one
+// 1024-thread workgroup per CU, persistent over a unit queue.  The unit's
+// input streams through a 64 KiB LDS ring (the 32 KiB window stays resident
+// next to the hash heads and chain links).  The 16 waves take items of 64
+// consecutive positions by ticket and carry each through
+//   insert  4-byte hash per position, wave-wide sort of (hash, lane) pairs for
+//           the predecessors inside the item, chains linked in item order
+//   search  one lane per position walks its chain (bounded depth) comparing
+//           up to 32 bytes per candidate; long matches then offer their
+//           distance to the other lanes of the wave and are extended
+//   parse   greedy / lazy successor per position, the positions the parse
+//           reaches by pointer doubling from the entry position the previous
+//           item hands over (the frontier, advanced under a try-lock)
+//   tokens  16-bit token slots to global memory at the base the frontier
+//           assigned, symbol histograms by LDS atomics
+// and every 1024 items (64 KiB of input) a block's histogram and token count
+// go to global memory.
+//
+// Emit kernel (zgpu_emit_kernel): one 256-thread workgroup per unit, eight per
+// CU, block after block:
+//   codes   length-limited Huffman code lengths + canonical codes (dynamic)
+//   header  run-length coded code lengths and the code-length code
+//   bits    per-token bit strings, prefix sum of bit lengths, LDS-staged
 //           OR-merge, coalesced dword stores
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -108,6 +120,7 @@ enum { M_SCAN = 0 /*[16]*/, M_UNIT = 32, M_NTOK = 34, M_TMP = 35, M_OVF = 36,
        M_LOADED = 44,  // input bytes resident in the ring (exclusive end)
        M_LOCK = 45,    // try-lock of the parse frontier
        M_SAFE = 46,    // the frontier may pass items below this without looking at M_OLDEST
+       M_LINKED = 47,  // all items below this have written their chain links
        M_OLDEST = 16   // [16] per wave: its oldest item whose tokens are not out yet (search kernel)
 };
 
@@ -121,12 +134,6 @@ struct Lds {
     __device__ uint32_t *misc() const { return (uint32_t *)(base + L_MISC); }
     __device__ uint8_t *scr() const { return base + L_SCR; }
 };
-
-__device__ inline uint32_t ld4u(const uint8_t *ring, uint32_t idx) {
-    const uint32_t *w = (const uint32_t *)(ring + (idx & ~3u));
-    uint32_t lo = w[0], hi = w[1];
-    return __builtin_amdgcn_alignbyte(hi, lo, idx & 3u);
-}
 
 // input bytes [lo, hi) of the unit -> ring (and the mirror of its first bytes);
 // lo is a multiple of 16.  `nthreads` threads with ids `t` cooperate.
@@ -213,27 +220,6 @@ __device__ inline uint32_t block_scan_excl(uint32_t v, uint32_t *total, uint32_t
     __syncthreads();
     *total = tot;
     return wsum + x - v;
-}
-
-// bitonic sort of n (power of two, <= 1024) u32 keys in LDS, ascending.
-__device__ inline void bitonic_sort(uint32_t *a, int n) {
-    const int t = threadIdx.x;
-    for (int k = 2; k <= n; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (t < n) {
-                int ixj = t ^ j;
-                if (ixj > t) {
-                    uint32_t x = a[t], y = a[ixj];
-                    bool up = (t & k) == 0;
-                    if ((x > y) == up) {
-                        a[t] = y;
-                        a[ixj] = x;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
 }
 
 // Wave-to-wave hand-off through one LDS word.  The LDS executes a wave's
@@ -598,6 +584,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
             if (tid == 0) {
                 misc[M_ITEM] = 0;
                 misc[M_LINK] = 0;
+                misc[M_LINKED] = 0;
                 misc[M_PARSE] = 0;
                 misc[M_ENTRY] = pr;
                 misc[M_NTOK] = 0;
@@ -866,16 +853,32 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     const bool live = key != 0xffffffffu;
                     const bool first = lane == 0 || (kp >> 6) != h;
                     const bool last = lane == 63 || (kn >> 6) != h || kn == 0xffffffffu;
-                    const uint32_t mypos = p0 + (key & 63u);
+                    uint32_t mypos = p0 + (key & 63u);
+                    // Everything the turn needs is in registers before the wait, and its two
+                    // accesses run on all lanes: a lane with no head to read reads any bucket and
+                    // ignores the value; a lane with no head to write writes its position into
+                    // its own link slot, which gets the real link right after the turn.
+                    uint32_t pp = p0 + (kp & 63u);
+                    uint32_t roff = L_HEAD + 2u * (live ? h : 0u);
+                    uint32_t woff = live && last ? roff : L_PREV + 2u * (mypos & WMASK);
+                    asm volatile("" : "+v"(roff), "+v"(woff), "+v"(mypos));
                     PH_END(9);
                     lds_wait_eq(&misc[M_LINK], k);
                     PH_END(10);
-                    if (live) {
-                        const uint32_t pp = first ? (uint32_t)head[h] : (p0 + (kp & 63u));
-                        prevt[mypos & WMASK] = (uint16_t)pp;
-                    }
-                    if (live && last) head[h] = (uint16_t)mypos;
+                    // The turn is held only for the exchange on the bucket heads: the read of the
+                    // old head and the write of the new one are issued in this order and the LDS
+                    // executes them in this order, so the turn passes on without waiting for the
+                    // read to come back.  The links that depend on it are written after that;
+                    // M_LINKED (all items below it have written their links) orders those writes
+                    // before any later item's walk.
+                    const uint32_t hv = *(const uint16_t *)(lds_raw + roff);
+                    *(uint16_t *)(lds_raw + woff) = (uint16_t)mypos;
                     lds_publish(&misc[M_LINK], k + 1);
+                    if (first) pp = hv;
+                    const uint32_t linked = lds_ld(&misc[M_LINKED]);
+                    if (live) prevt[mypos & WMASK] = (uint16_t)pp;
+                    if (linked != k) lds_wait_eq(&misc[M_LINKED], k);
+                    lds_publish(&misc[M_LINKED], k + 1);
                 }
                 PH_END(11);
                 // ---- search ----
