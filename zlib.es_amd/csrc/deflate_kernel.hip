@@ -111,7 +111,7 @@ constexpr uint32_t H_CLF = 640;    // u32[32] code-length symbol freqs
 constexpr uint32_t H_CLTAB = 768;  // u32[32]
 constexpr uint32_t E_TOTAL = E_HUF + H_END;
 
-// misc words (search kernel: M_UNIT, M_NTOK, M_ITEM..; emit kernel: M_SCAN, M_UNIT, M_NTOK, M_TMP, M_OVF)
+// misc words (search kernel: M_NTOK, M_OLDEST, M_ITEM.., M_NEXT..; emit kernel: M_SCAN, M_UNIT, M_NTOK, M_TMP, M_OVF)
 enum { M_SCAN = 0 /*[16]*/, M_UNIT = 32, M_NTOK = 34, M_TMP = 35, M_OVF = 36,
        M_ITEM = 40,    // next item to hand out
        M_LINK = 41,    // item whose turn it is to link its hash chains
@@ -121,6 +121,7 @@ enum { M_SCAN = 0 /*[16]*/, M_UNIT = 32, M_NTOK = 34, M_TMP = 35, M_OVF = 36,
        M_LOCK = 45,    // try-lock of the parse frontier
        M_SAFE = 46,    // the frontier may pass items below this without looking at M_OLDEST
        M_LINKED = 47,  // all items below this have written their chain links
+       M_NEXT = 48,    // [9] the next unit: index, input offset (2), size, priming bytes, token offset (2), first block; tag
        M_OLDEST = 16   // [16] per wave: its oldest item whose tokens are not out yet (search kernel)
 };
 
@@ -552,23 +553,55 @@ __device__ __forceinline__ void search_units(const Params &P) {
     uint8_t *scr = L.scr();
     PH_DECL;
 
+    // The next unit's queue ticket and its entries of the unit tables are fetched by thread 0
+    // while the current unit is being worked on, and wait in LDS (M_NEXT..): taking a unit then
+    // costs no global round trips (they are three dependent ones: ticket, offsets, data, and
+    // with one workgroup per CU nothing else would hide them), only the load of its first bytes.
+    auto fetch_unit = [&](uint32_t tag) {
+        const uint32_t nu = P.unit_first + atomicAdd(P.counter, 1u);
+        uint64_t uo = 0, to = 0;
+        uint32_t nn = 0, prm = 0, bf = 0;
+        if (nu < P.unit_end) {
+            uo = P.in_off[nu];
+            nn = (uint32_t)(P.in_off[nu + 1] - uo);
+            prm = nn ? P.unit_prime[nu] : 0u;
+            to = P.tok_off[nu];
+            bf = P.blk_first[nu];
+        }
+        misc[M_NEXT + 0] = nu;
+        misc[M_NEXT + 1] = (uint32_t)uo;
+        misc[M_NEXT + 2] = (uint32_t)(uo >> 32);
+        misc[M_NEXT + 3] = nn;
+        misc[M_NEXT + 4] = prm;
+        misc[M_NEXT + 5] = (uint32_t)to;
+        misc[M_NEXT + 6] = (uint32_t)(to >> 32);
+        misc[M_NEXT + 7] = bf;
+        asm volatile("" ::: "memory");
+        lds_st(&misc[M_NEXT + 8], tag);  // the entries above are complete (LDS stores land in order)
+    };
+    if (tid == 0) fetch_unit(0u);
+    __syncthreads();
+    // The next unit's first 16 KiB, 16 bytes per thread, requested when a wave runs out of
+    // items in the current unit's last block and kept in registers until the unit changes.
+    uint4 pf = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t pf_hi = 0;  // bytes [0, pf_hi) of the next unit are covered that way (uniform)
     for (;;) {
-        if (tid == 0) misc[M_UNIT] = P.unit_first + atomicAdd(P.counter, 1u);
-        __syncthreads();
-        const uint32_t u = misc[M_UNIT];
-        __syncthreads();
+        // written before the barrier that ended the previous unit; overwritten only after the
+        // barrier that ends this unit's init
+        const uint32_t u = misc[M_NEXT + 0];
         if (u >= P.unit_end) break;
 
         // A unit that continues a stream starts `pr` bytes early: those bytes (the end of the
         // previous unit) go through the insert step only, so matches may reach back into them
         // as a decoder of the concatenated stream can; tokens start at position pr.
-        const uint64_t uoff = P.in_off[u];
-        const uint32_t n_unit = (uint32_t)(P.in_off[u + 1] - uoff);
-        const uint32_t pr = n_unit ? P.unit_prime[u] : 0u;
+        const uint64_t uoff = (uint64_t)misc[M_NEXT + 1] | (uint64_t)misc[M_NEXT + 2] << 32;
+        const uint32_t n_unit = misc[M_NEXT + 3];
+        const uint32_t pr = misc[M_NEXT + 4];
         const uint8_t *in = P.in + uoff - pr;
         const uint32_t n = n_unit + pr;
         const uint32_t prime_items = pr >> 6;
-        uint16_t *tokbuf = P.tok + P.tok_off[u];  // of the block in progress
+        uint16_t *tokbuf = P.tok + ((uint64_t)misc[M_NEXT + 5] | (uint64_t)misc[M_NEXT + 6] << 32);  // of the block in progress
+        const uint32_t unit_blk_first = misc[M_NEXT + 7];
 
         // ---- unit init ----
         for (int i = tid; i < (1 << HBITS) / 8; i += WG)
@@ -580,7 +613,12 @@ __device__ __forceinline__ void search_units(const Params &P) {
         {
             // first 32 KiB of the unit -> ring (all threads)
             const uint32_t hi = n < 2 * REFILL ? n : 2 * REFILL;
-            load_ring(ring, in, 0, hi, tid, WG, aligned);
+            if ((uint32_t)tid * 16u < pf_hi) {
+                *(uint4 *)(ring + tid * 16) = pf;
+                if ((uint32_t)tid * 16u < RING_PAD) *(uint4 *)(ring + RING + tid * 16) = pf;
+            }
+            load_ring(ring, in, pf_hi, hi, tid, WG, aligned);
+            pf_hi = 0;
             if (tid == 0) {
                 misc[M_ITEM] = 0;
                 misc[M_LINK] = 0;
@@ -598,11 +636,12 @@ __device__ __forceinline__ void search_units(const Params &P) {
         }
         __syncthreads();
         PH_END(0);
+        if (tid == 0) fetch_unit(u + 1);
 
         // ---- a block is done: end-of-block token, token count and histograms to global
         // memory for the emit kernel; the block state starts over ----
         auto flush_block = [&](uint32_t blk) {
-            const uint32_t gb = P.blk_first[u] + blk;
+            const uint32_t gb = unit_blk_first + blk;
             if (tid == 0) {
                 const uint32_t nt = misc[M_NTOK];
                 tokbuf[nt] = 256;
@@ -1037,6 +1076,20 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 // frontier on its way here either sees the stamp, or publishes M_PARSE = k after
                 // this look and then looks at the stamp again (the check after its unlock).
                 if (lds_ld(&misc[M_PARSE]) == k) try_advance();
+            }
+            if (blk_end == nitems) {
+                // out of items in the unit's last block: request the next unit's first bytes
+                // now, so that they travel while the waves drain and meet at the barrier
+                lds_wait_eq(&misc[M_NEXT + 8], u + 1);
+                if (misc[M_NEXT + 0] < P.unit_end) {
+                    const uint32_t npr = misc[M_NEXT + 4];
+                    const uint8_t *nin = P.in + ((uint64_t)misc[M_NEXT + 1] | (uint64_t)misc[M_NEXT + 2] << 32) - npr;
+                    const uint32_t nn = misc[M_NEXT + 3] + npr;
+                    if ((((uintptr_t)nin) & 15u) == 0) {
+                        pf_hi = (nn < REFILL ? nn : REFILL) & ~15u;
+                        if ((uint32_t)tid * 16u < pf_hi) pf = *(const uint4 *)(nin + tid * 16);
+                    }
+                }
             }
             while (npend > 0) emit_oldest(blk_end, true);
             // also a wave that got no item in this block must not hold the frontier back
