@@ -737,6 +737,8 @@ __device__ __forceinline__ void search_units(const Params &P) {
             int npend = 0;
             // item; per lane: the position's byte << 24 | best length << 15 | best distance - 1
             uint32_t q_k[PEND], q_ld[PEND];
+            // per lane: the item's positions on the parse path that starts at this lane (bit i: local index i)
+            uint32_t q_rlo[PEND], q_rhi[PEND];
             // kind / successor of every local index of an item (0 literal, 1 match here,
             // 2 literal + match at +1); no look-ahead across the item boundary
             auto successor = [&](uint32_t best_len, uint32_t l1, uint32_t &kind) -> uint32_t {
@@ -760,10 +762,10 @@ __device__ __forceinline__ void search_units(const Params &P) {
             // and, if so, where the item's tokens start.
             auto emit_oldest = [&](uint32_t cur, bool must) -> bool {
                 // ---- tokens of item q_k[0]: lane l <-> local index l ----
-                // The parse path through the item is walked on scalar registers: literal runs
-                // are skipped with a find-first-set over the ballot of match positions, a
-                // match costs one readlane of its successor.  The path mask then gives every
-                // lane its place in the token stream by bit counts; no shuffles.
+                // The positions the parse visits in the item were collected per starting index
+                // when the item was prepared; the set for the actual entry index comes by two
+                // readlanes.  That path mask gives every lane its place in the token stream by
+                // bit counts; no shuffles.
                 const uint32_t k0 = q_k[0], ld = q_ld[0];
                 const uint32_t p0 = k0 << 6, sl = k0 & (NSLOT_E - 1);
                 const uint32_t seg_end = (n - p0) < 64u ? (n - p0) : 64u;
@@ -796,18 +798,10 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 const uint32_t J = successor((ld >> 15) & 0x1ffu, (ldn >> 15) & 0x1ffu, kind);
                 const unsigned long long valid = seg_end == 64u ? ~0ull : ((1ull << seg_end) - 1ull);
                 const unsigned long long M = __ballot(kind != 0) & valid;
+                // the positions the parse visits in the item: the set that prep built for the
+                // lane at the entry index (two readlanes, no walk)
                 unsigned long long path = 0;
-                for (uint32_t pos = e; pos < seg_end;) {
-                    const unsigned long long rest = M >> pos;
-                    if (!rest) {
-                        path |= ~0ull << pos;
-                        break;
-                    }
-                    const uint32_t d = (uint32_t)__builtin_ctzll(rest);
-                    path |= ((2ull << d) - 1ull) << pos;  // literals pos .. pos+d-1 and the match at pos+d
-                    pos = rl(J, pos + d);
-                }
-                path &= valid;
+                if (e < seg_end) path = ((unsigned long long)rl(q_rhi[0], e) << 32 | rl(q_rlo[0], e)) & valid;
                 const unsigned long long two = path & __ballot(kind == 2);
                 const bool on = (path >> lane) & 1ull;
                 if (on) {
@@ -840,6 +834,8 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 for (int i = 0; i + 1 < PEND; ++i) {
                     q_k[i] = q_k[i + 1];
                     q_ld[i] = q_ld[i + 1];
+                    q_rlo[i] = q_rlo[i + 1];
+                    q_rhi[i] = q_rhi[i + 1];
                 }
                 --npend;
                 PH_END(7);
@@ -1037,6 +1033,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 }
                 PH_END(13);
                 PH_START();
+                uint32_t r_lo, r_hi;
                 {
                     // ---- exit index and token count of every local index (six doubling steps) ----
                     const uint32_t seg_end = (n - p0) < 64u ? (n - p0) : 64u;
@@ -1045,14 +1042,21 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     uint32_t J = successor(best_len, l1, kind);
                     if ((uint32_t)lane >= seg_end) J = (uint32_t)lane;  // past the end: stay put
                     uint32_t Cn = (uint32_t)lane < seg_end ? 1u + kind : 0u;  // slots: literal 1, match 2, literal + match 3
+                    // and the positions visited on the way (this one included), for the token step
+                    r_lo = (uint32_t)lane < seg_end && lane < 32 ? 1u << lane : 0u;
+                    r_hi = (uint32_t)lane < seg_end && lane >= 32 ? 1u << (lane - 32) : 0u;
 #pragma unroll
                     for (int r = 0; r < 6; ++r) {
                         // every index already leaves the item (long matches): nothing left to double
                         if (!__ballot(J < seg_end)) break;
                         // exit and count travel together: one permute per doubling step
-                        const uint32_t t = (uint32_t)__shfl((int)(J | Cn << 16), (int)(J & 63u), 64);
+                        const int src = (int)(J & 63u);
+                        const uint32_t t = (uint32_t)__shfl((int)(J | Cn << 16), src, 64);
+                        const uint32_t tl = (uint32_t)__shfl((int)r_lo, src, 64), th = (uint32_t)__shfl((int)r_hi, src, 64);
                         const bool inb = J < seg_end;
                         Cn += inb ? t >> 16 : 0u;
+                        r_lo |= inb ? tl : 0u;
+                        r_hi |= inb ? th : 0u;
                         J = inb ? (t & 0xffffu) : J;
                     }
                     const uint32_t sl = k & (NSLOT - 1);
@@ -1069,6 +1073,8 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     if (i == npend) {
                         q_k[i] = k;
                         q_ld[i] = (own.x & 0xffu) << 24 | best_len << 15 | ((best_dist - 1) & 0x7fffu);
+                        q_rlo[i] = r_lo;
+                        q_rhi[i] = r_hi;
                     }
                 ++npend;
                 lds_publish(&slot_done[k & (NSLOT - 1)], k + 1);
