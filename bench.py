@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--chain", type=int, default=0, help="hash-chain search depth (0 = library default)")
     ap.add_argument("--nice", type=int, default=32)
+    ap.add_argument("--deep", type=int, default=-1, help="long-match deep-walk budget (-1 = library default)")
+    ap.add_argument("--fan", type=int, default=-1, help="probe-ahead fans per 64 bytes (-1 = library default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,6 +138,10 @@ def main():
     N = z._native
     if args.chain or args.nice != 32:
         z.set_search(args.chain or z._native.DEFAULT_MAX_CHAIN, args.nice)
+
+    if args.deep >= 0 or args.fan >= 0:
+        N.set_long_match(args.deep if args.deep >= 0 else N.DEFAULT_DEEP_CHAIN,
+                         args.fan if args.fan >= 0 else N.DEFAULT_PROBE_FANS)
 
     def barrier():
         torch.cuda.synchronize()

@@ -87,6 +87,19 @@ int zgpu_last_hip_error(void);
  * default; (8, 258) costs about 40 % of the speed and makes highly repetitive
  * input up to 15 % smaller. */
 int zgpu_set_search(int max_chain, int nice_length);
+/* Long matches.  A position whose match reaches the 32-byte compare length and
+ * does not merely continue its predecessor's match is where a parse may need
+ * more than the nearest long candidate; the reference finds the longest of all
+ * (src/rawdeflate.js:370-395).  deep_chain: further candidates such a position
+ * examines along its chain, each looked at only if it agrees in the byte after
+ * the current best (0..32768, default 0: every step is a dependent LDS round
+ * trip, about 1 % of the throughput on repetitive input per step).
+ * probe_fans: such positions per 64 input bytes whose match lies at most 16
+ * bytes back (runs, short periods) that also try the distances at which the
+ * positions up to 256 bytes after them repeat (0..64, default 1).  (32, 3)
+ * brings runs of incrementing bytes from 1.27-1.35 x the reference's size to
+ * 1.02-1.04 x at about 70 % of the default's speed. */
+int zgpu_set_long_match(int deep_chain, int probe_fans);
 /* In a batch of fewer than 16 units per compute unit, a unit longer than two
  * pieces is cut into pieces (batch bytes / 16 / compute units, at least
  * 128 KiB, at most piece_bytes) which are compressed side by side as chunks of

@@ -98,20 +98,49 @@ def test_roundtrip_golden_cases(z, golden, ctype):
                 assert s == c["raw"]["0"]["len"]  # stored framing is byte-identical in size
 
 
+# Size against the reference, case by case, at the shipped search settings.  Cases not listed
+# here meet the 3 % bar on their own; the listed ones are the known exceptions of the bounded
+# search, held to what was measured (+1 %) so that they cannot get worse unnoticed:
+# (generator, compressionType) -> bound.
+DEFAULT_EXCEPTIONS = {
+    ("rndseq", 1): 1.37, ("rndseq", 2): 1.29,            # the longest of ~100 equally near candidates is needed
+    ("small-alpha", 1): 1.29, ("small-alpha", 2): 1.07,  # 2-3 letter alphabets: thousands of candidates per key
+    ("runs", 1): 1.06,                                   # 4-value runs (1.19 before the probe-ahead step)
+}
+
+
+def _case_bound(case, ctype, exceptions):
+    return exceptions.get((case["spec"]["gen"], ctype), RATIO_BAR)
+
+
 @pytest.mark.parametrize("ctype", [1, 2])
-def test_ratio_vs_reference(z, golden, ctype):
-    # total over the compressible named cases; the reference sizes are the golden ones
-    tot_gpu = tot_ref = 0
-    datas, refs = [], []
-    for c in golden["cases"]:
-        if c["n"] >= 16384:
-            datas.append(zo.gen(c["spec"]))
-            refs.append(c["raw"][str(ctype)]["len"])
+def test_ratio_vs_reference_case_by_case(z, golden, ctype):
+    # every named case of 16 KiB and more on its own (the reference sizes are the golden ones)
+    cases = [c for c in golden["cases"] if c["n"] >= 16384]
+    datas = [zo.gen(c["spec"]) for c in cases]
     sizes = _roundtrip(z, datas, ctype)
-    for c, s, r in zip(datas, sizes, refs):
-        tot_gpu += s
-        tot_ref += r
-    assert tot_gpu <= RATIO_BAR * tot_ref, (tot_gpu, tot_ref)
+    bad = [(c["spec"], s, c["raw"][str(ctype)]["len"]) for c, s in zip(cases, sizes)
+           if s > _case_bound(c, ctype, DEFAULT_EXCEPTIONS) * c["raw"][str(ctype)]["len"]]
+    assert not bad, bad
+    assert sum(sizes) <= RATIO_BAR * sum(c["raw"][str(ctype)]["len"] for c in cases)
+
+
+@pytest.mark.parametrize("ctype", [1, 2])
+def test_ratio_with_long_match_steps(z, golden, ctype):
+    # deep walk 56 + three probe-ahead fans: runs of incrementing bytes (the reference's own
+    # gzip-test input) come within the bar, at about 60 % of the default's speed
+    cases = [c for c in golden["cases"] if c["n"] >= 16384]
+    datas = [zo.gen(c["spec"]) for c in cases]
+    z._native.set_long_match(56, 3)
+    try:
+        sizes = _roundtrip(z, datas, ctype)
+    finally:
+        z._native.set_long_match()
+    exceptions = {k: v for k, v in DEFAULT_EXCEPTIONS.items() if k[0] != "rndseq"}
+    exceptions["runs", 1] = 1.05
+    bad = [(c["spec"], s, c["raw"][str(ctype)]["len"]) for c, s in zip(cases, sizes)
+           if s > _case_bound(c, ctype, exceptions) * c["raw"][str(ctype)]["len"]]
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("ctype", [1, 2])

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import zlib_es_amd as z  # noqa: E402
 
-PHASES = ["load", "blkwait", "-", "-", "-", "-", "-", "emit-tok", "lag+ld", "sort", "linkwait", "link", "pass1", "pass2", "prep", "parsewait"]
+PHASES = ["load", "blkwait", "deep", "fan", "-", "-", "-", "emit-tok", "lag+ld", "sort", "linkwait", "link", "pass1", "pass2", "prep", "parsewait"]
 
 
 def run(name, data, nu, ub, ctype, lazy):
@@ -46,6 +46,8 @@ def run(name, data, nu, ub, ctype, lazy):
 
 def main():
     nu, ub = int(os.environ.get("NU", 2048)), int(os.environ.get("UB", 65536))
+    if "LONG" in os.environ:  # "deep:fan"
+        z._native.set_long_match(*[int(x) for x in os.environ["LONG"].split(":")])
     if "CHAIN" in os.environ:  # default: the library's own search depth
         z.set_search(int(os.environ["CHAIN"]), int(os.environ.get("NICE", "32")))
     dev = torch.device("cuda")

@@ -18,7 +18,7 @@ F_FINAL_EACH, F_SYNC_ALIGN, F_FINAL_LAST, F_PRIME_WINDOW, F_WANT_CRC, F_WANT_ADL
 # every symbol include/zgpu.h declares
 SYMBOLS = [
     "zgpu_init", "zgpu_shutdown", "zgpu_strerror", "zgpu_last_hip_error", "zgpu_set_search", "zgpu_set_split",
-    "zgpu_set_min_lazy",
+    "zgpu_set_min_lazy", "zgpu_set_long_match",
     "zgpu_deflate_bound", "zgpu_deflate_batch", "zgpu_deflate_batch_begin", "zgpu_deflate_batch_finish",
     "zgpu_job_release", "zgpu_plan_create", "zgpu_plan_destroy",
     "zgpu_plan_out_bound", "zgpu_plan_run", "zgpu_plan_out_off_device", "zgpu_plan_crc_device",
@@ -60,6 +60,8 @@ def lib():
     L.zgpu_set_split.argtypes = [C.c_uint64]
     L.zgpu_set_min_lazy.restype = i32
     L.zgpu_set_min_lazy.argtypes = [i32]
+    L.zgpu_set_long_match.restype = i32
+    L.zgpu_set_long_match.argtypes = [i32, i32]
     L.zgpu_deflate_bound.restype = u64
     L.zgpu_deflate_bound.argtypes = [u64]
     L.zgpu_deflate_batch.restype = i32
@@ -127,6 +129,14 @@ DEFAULT_MAX_CHAIN, DEFAULT_NICE_LENGTH = 8, 32
 def set_search(max_chain=DEFAULT_MAX_CHAIN, nice_length=DEFAULT_NICE_LENGTH):
     """Engine-wide search settings; without arguments back to the library's defaults."""
     _check(lib().zgpu_set_search(max_chain, nice_length), "zgpu_set_search")
+
+
+DEFAULT_DEEP_CHAIN, DEFAULT_PROBE_FANS = 0, 1
+
+
+def set_long_match(deep_chain=DEFAULT_DEEP_CHAIN, probe_fans=DEFAULT_PROBE_FANS):
+    """Bounds of the search kernel's long-match steps; without arguments back to the defaults."""
+    _check(lib().zgpu_set_long_match(deep_chain, probe_fans), "zgpu_set_long_match")
 
 
 def set_split(piece_bytes):

@@ -57,7 +57,9 @@ constexpr uint32_t RING_PAD = 272;  // mirror of ring[0..272) after the end
 constexpr uint32_t WMASK = 0x7fff;  // chain slots (32 Ki positions)
 constexpr int PEND = 2;             // searched items a wave may hold before it must parse the oldest
 constexpr uint32_t LAG = 48;        // an item starts only when all items more than LAG back are parsed
-constexpr uint32_t MAXDIST = 32768 - 64 * LAG - 128;  // window minus the span of in-flight items
+constexpr uint32_t FAN_MAXDIST = 16;  // probe-ahead fans start from matches at most this far back
+constexpr uint32_t AHEAD = 4;         // the chains are linked this many items ahead of the search
+constexpr uint32_t MAXDIST = 32768 - 64 * (LAG + AHEAD) - 128;  // window minus the span of in-flight items
 constexpr uint32_t BLK_ITEMS = 1024;  // one DEFLATE block per 64 KiB of input
 constexpr uint32_t LOOKAHEAD = 64 + 6 * 64 + 258 + 16;  // bytes an item may read past its start
 constexpr uint32_t REFILL = 16384;  // ring refill granule
@@ -532,6 +534,7 @@ struct Params {
     uint32_t *counter;          // unit queue head (relative to unit_first)
     uint32_t unit_first, unit_end;
     int lazy, max_chain, nice;
+    int deep, fan;              // long-match steps: deep-walk budget, probe-ahead fans per item (0 = off)
     const uint32_t *unit_prime; // per unit: bytes before it (same stream, multiple of 64, <= 32 KiB) that prime its window
     unsigned long long *prof;   // 16 phase counters (diagnostic builds) or null
 };
@@ -843,26 +846,33 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 return true;
             };
             for (;;) {
-                uint32_t k = 0;
-                if (lane == 0) k = atomicAdd(&misc[M_ITEM], 1u);
-                k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-                if (k >= blk_end) break;
+                // A ticket t links item t into the chains and searches item t - AHEAD: the
+                // chains run AHEAD items ahead of the search, so a searched position may follow
+                // the links of the positions up to 256 bytes after it (the probe-ahead step).
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(&misc[M_ITEM], 1u);
+                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                if (t >= blk_end + AHEAD) break;
+                const bool has_search = t >= AHEAD;  // tickets below AHEAD (the unit's first) only link
+                const uint32_t k = t - AHEAD;        // the searched item (valid when has_search)
                 PH_START();
-                if (npend == 0) {
-                    // nothing older waits in this wave (its first item of the block)
-                    lds_publish(&misc[M_OLDEST + (tid >> 6)], k);
-                    try_advance();
+                if (has_search) {
+                    if (npend == 0) {
+                        // nothing older waits in this wave (its first item of the block)
+                        lds_publish(&misc[M_OLDEST + (tid >> 6)], k);
+                        try_advance();
+                    }
+                    // An unparsed item more than LAG items back must be parsed first, or the
+                    // waves that wait for it below could never be released.
+                    while (npend > 0 && k > q_k[0] + LAG) emit_oldest(k, true);
+                    // bound the spread of in-flight items: everything more than LAG items back is
+                    // parsed, so no wave still reads ring bytes or chain slots that get recycled
+                    if (k > LAG) lds_wait_ge(&misc[M_PARSE], k - LAG);
                 }
-                const uint32_t p0 = k << 6;
+                const uint32_t p0 = has_search ? k << 6 : 0u;
                 const uint32_t p = p0 + (uint32_t)lane;
-                // An unparsed item more than LAG items back must be parsed first, or the
-                // waves that wait for it below could never be released.
-                while (npend > 0 && k > q_k[0] + LAG) emit_oldest(k, true);
-                // bound the spread of in-flight items: everything more than LAG items back is
-                // parsed, so no wave still reads ring bytes or chain slots that get recycled
-                if (k > LAG) lds_wait_ge(&misc[M_PARSE], k - LAG);
                 // ring refill every 16 KiB, by the wave that crosses the boundary
-                if (k && (p0 & (REFILL - 1)) == 0) {
+                if (has_search && k && (p0 & (REFILL - 1)) == 0) {
                     uint32_t lo = p0 + REFILL, hi = p0 + 2 * REFILL;
                     if (hi > n) hi = n;
                     if (lo < hi) {
@@ -871,34 +881,39 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     }
                 }
                 {
-                    uint32_t need = p0 + LOOKAHEAD;
+                    uint32_t need = p0 + LOOKAHEAD;  // covers the linked item (AHEAD items on) as well
                     if (need > n) need = n;
                     lds_wait_ge(&misc[M_LOADED], need);
                 }
                 PH_END(8);
-                // ---- insert: sort (hash, lane) in registers, link chains in item order ----
-                // this position's first 16 bytes: hashed here, compared against candidates below
+                // this position's first 16 bytes: compared against candidates below
                 const v4u own = ld16(ring, p & (RING - 1));
-                uint32_t key = 0xffffffffu;
-                if (p + 4 <= n) key = (hash4(own.x) << 6) | (uint32_t)lane;  // all four bytes inside the unit
-                key = wave_sort64(key);
-                {
+                // ---- insert item t: sort (hash, lane) in registers, link chains in item order ----
+                if (t < nitems) {
+                    const uint32_t ip0 = t << 6, ip = ip0 + (uint32_t)lane;
+                    uint32_t key = 0xffffffffu;
+                    {
+                        const uint32_t *w = (const uint32_t *)(ring + (ip & (RING - 1) & ~3u));
+                        const uint32_t first4 = __builtin_amdgcn_alignbyte(w[1], w[0], ip & 3u);
+                        if (ip + 4 <= n) key = (hash4(first4) << 6) | (uint32_t)lane;  // all four bytes inside the unit
+                    }
+                    key = wave_sort64(key);
                     const uint32_t kp = from_below(key, 0u), kn = from_above(key, 0xffffffffu);
                     const uint32_t h = key >> 6;
                     const bool live = key != 0xffffffffu;
                     const bool first = lane == 0 || (kp >> 6) != h;
                     const bool last = lane == 63 || (kn >> 6) != h || kn == 0xffffffffu;
-                    uint32_t mypos = p0 + (key & 63u);
+                    uint32_t mypos = ip0 + (key & 63u);
                     // Everything the turn needs is in registers before the wait, and its two
                     // accesses run on all lanes: a lane with no head to read reads any bucket and
                     // ignores the value; a lane with no head to write writes its position into
                     // its own link slot, which gets the real link right after the turn.
-                    uint32_t pp = p0 + (kp & 63u);
+                    uint32_t pp = ip0 + (kp & 63u);
                     uint32_t roff = L_HEAD + 2u * (live ? h : 0u);
                     uint32_t woff = live && last ? roff : L_PREV + 2u * (mypos & WMASK);
                     asm volatile("" : "+v"(roff), "+v"(woff), "+v"(mypos));
                     PH_END(9);
-                    lds_wait_eq(&misc[M_LINK], k);
+                    lds_wait_eq(&misc[M_LINK], t);
                     PH_END(10);
                     // The turn is held only for the exchange on the bucket heads: the read of the
                     // old head and the write of the new one are issued in this order and the LDS
@@ -908,21 +923,97 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     // before any later item's walk.
                     const uint32_t hv = *(const uint16_t *)(lds_raw + roff);
                     *(uint16_t *)(lds_raw + woff) = (uint16_t)mypos;
-                    lds_publish(&misc[M_LINK], k + 1);
+                    lds_publish(&misc[M_LINK], t + 1);
                     if (first) pp = hv;
                     const uint32_t linked = lds_ld(&misc[M_LINKED]);
                     if (live) prevt[mypos & WMASK] = (uint16_t)pp;
-                    if (linked != k) lds_wait_eq(&misc[M_LINKED], k);
-                    lds_publish(&misc[M_LINKED], k + 1);
+                    if (linked != t) lds_wait_eq(&misc[M_LINKED], t);
+                    lds_publish(&misc[M_LINKED], t + 1);
+                } else {
+                    // past the unit's last item: the items this search reads links of are all linked
+                    lds_wait_ge(&misc[M_LINKED], nitems);
                 }
                 PH_END(11);
+                if (!has_search) continue;
                 // ---- search ----
                 uint32_t best_len = 0, best_dist = 0;
                 if (k >= prime_items) {  // priming items are only inserted
                     const uint32_t maxlen = p < n ? ((n - p) < 258u ? (n - p) : 258u) : 0u;
                     const uint32_t limit = p < MAXDIST ? p : MAXDIST;
+                    const uint32_t pi = p & (RING - 1);
                     uint32_t blen = 2;
-                    {
+                    uint32_t c = 0, last = 0xffffu;  // the walk's next candidate and last distance (last = 0xffff: walk over)
+                    // A distance scored for all 64 positions of the item at once: one byte compare
+                    // per lane, a ballot, and count-trailing-ones give every lane its exact match
+                    // length (up to 258) at that distance; a lane keeps it if it is longer than
+                    // what it has (or as long and nearer).
+                    auto score_distance = [&](uint32_t d) {
+                        uint32_t run;
+                        bool open;
+                        {
+                            const bool eq = p < n && p >= d && (own.x & 0xffu) == ring[(p - d) & (RING - 1)];
+                            // zeros shifted in from the top read as mismatches after the inversion
+                            const unsigned long long inv = ~(__ballot(eq) >> lane);
+                            run = inv ? (uint32_t)__builtin_ctzll(inv) : 64u;
+                            open = run == 64u - (uint32_t)lane;
+                        }
+                        // Beyond the item every match that is still open continues the same way:
+                        // one number, how far the data at p0 + 64 goes on matching at this
+                        // distance.  Four positions per lane and step: an aligned dword against
+                        // a dword shifted into place, first differing byte by find-first-set,
+                        // first differing lane by ballot.
+                        if (__ballot(open)) {
+                            // both steps' bytes are requested together: one LDS round trip
+                            uint32_t xs[2];
+#pragma unroll
+                            for (uint32_t st = 0; st < 2; ++st) {
+                                const uint32_t q4 = p0 + 64u + (st << 8) + ((uint32_t)lane << 2);
+                                const uint32_t a = *(const uint32_t *)(ring + (q4 & (RING - 1)));
+                                const uint32_t s4 = q4 - d;
+                                const uint32_t b0 = *(const uint32_t *)(ring + (s4 & (RING - 1) & ~3u));
+                                const uint32_t b1 = *(const uint32_t *)(ring + ((s4 + 4u) & (RING - 1) & ~3u));
+                                uint32_t x = a ^ __builtin_amdgcn_alignbyte(b1, b0, s4 & 3u);
+                                // positions past the unit's end differ by decree
+                                const uint32_t left = q4 < n ? n - q4 : 0u;
+                                if (left < 4u) x |= left ? 0xffffffffu << (left << 3) : 0xffffffffu;
+                                xs[st] = x;
+                            }
+                            uint32_t ext = 512u;
+                            const unsigned long long m0 = __ballot(xs[0] != 0u);
+                            if (m0) {
+                                const uint32_t fl_ = (uint32_t)__builtin_ctzll(m0);
+                                ext = (fl_ << 2) + (rl(ffbl(xs[0]), fl_) >> 3);
+                            } else {
+                                const unsigned long long m1 = __ballot(xs[1] != 0u);
+                                if (m1) {
+                                    const uint32_t fl_ = (uint32_t)__builtin_ctzll(m1);
+                                    ext = 256u + (fl_ << 2) + (rl(ffbl(xs[1]), fl_) >> 3);
+                                }
+                            }
+                            if (open) run += ext;
+                        }
+                        if (run > maxlen) run = maxlen;
+                        if (run >= 3 && d <= limit && (run > blen || (run == blen && d < best_dist))) {
+                            blen = run;
+                            best_dist = d;
+                        }
+                    };
+                    // An item whose 64 positions all repeat at one distance (long runs, long copies) takes
+                    // that distance and skips the walks: tried only when the first and the last position's
+                    // nearest candidates lie at the same distance, which the links alone tell.
+                    bool whole = false;
+                    if (p + 4 <= n) c = prevt[p & WMASK];
+                    if (!THOROUGH && p0 + 67u <= n) {
+                        const uint32_t d0 = (p0 - rl(c, 0)) & 0xffffu, d63 = (p0 + 63u - rl(c, 63)) & 0xffffu;
+                        if (d0 == d63 && d0 >= 1u && d0 <= (p0 < MAXDIST ? p0 : MAXDIST)) {
+                            const bool eq = (own.x & 0xffu) == ring[(p - d0) & (RING - 1)];
+                            if (__ballot(eq) == ~0ull) {
+                                score_distance(d0);
+                                whole = true;
+                            }
+                        }
+                    }
+                    if (!whole) {
                         // pass 1, lane per position: walk the hash chain.  A candidate costs one
                         // LDS round trip: its chain link and its first 16 bytes (aligned dword
                         // reads, see ld16) are fetched together and compared against this
@@ -930,14 +1021,15 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         // loop for the wave to diverge on.  Only a candidate that matches all 16
                         // bytes reads 16 more (CMP_CAP; pass 2 finds the exact length of long
                         // matches).
-                        const uint32_t pi = p & (RING - 1);
                         const uint32_t cmpmax = maxlen < CMP_CAP ? maxlen : CMP_CAP;
                         if (p + 4 <= n) {
-                            uint32_t c = prevt[p & WMASK];
-                            uint32_t last = 0;
+                            last = 0;
                             for (int budget = P.max_chain; budget > 0; --budget) {
                                 const uint32_t dist = (p - c) & 0xffffu;
-                                if (dist <= last || dist > limit) break;
+                                if (dist <= last || dist > limit) {
+                                    last = 0xffffu;
+                                    break;
+                                }
                                 last = dist;
                                 const uint32_t ci = c & (RING - 1);
                                 const uint32_t nxt = prevt[c & WMASK];
@@ -957,24 +1049,23 @@ __device__ __forceinline__ void search_units(const Params &P) {
                                 } else if (len > cmpmax) {
                                     len = cmpmax;
                                 }
+                                c = nxt;
                                 if (len > blen) {
                                     blen = len;
                                     best_dist = dist;
                                     // as long as the unit allows, or as long as the caller finds nice
                                     // (nice <= CMP_CAP, the default: the first capped candidate ends
-                                    // the walk and pass 2 finds its exact length)
+                                    // the walk; pass 2 finds its exact length and the long-match
+                                    // steps below look for longer ones)
                                     if (len >= maxlen || len >= (uint32_t)P.nice) break;
                                 }
-                                c = nxt;
                             }
                         }
                     }
                     PH_END(12);
-                    {
+                    if (!whole) {
                         // pass 2, distance sharing across the wave: a distance that gave one
-                        // lane a long match is scored for all 64 positions at once -- one byte
-                        // compare per lane, a ballot, and count-trailing-ones give every lane
-                        // its exact match length (up to 258) at that distance.
+                        // lane a long match is scored for all 64 positions at once.
                         // Offers: every lane's best distance if it is long enough to be worth
                         // sharing.
                         const uint32_t offer = best_dist;
@@ -983,51 +1074,189 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         for (int it = 0; it < share_iters; ++it) {
                             if (!todo) break;
                             const uint32_t d = rl(offer, (uint32_t)__builtin_ctzll(todo));  // a uniform lane: v_readlane, no LDS
-                            // the item's own 64 positions: one byte compare per lane (the item's bytes
-                            // are in registers), a ballot, count-trailing-ones of the shifted mask
-                            uint32_t run;
-                            bool open;
-                            {
-                                const bool eq = p < n && p >= d && (own.x & 0xffu) == ring[(p - d) & (RING - 1)];
-                                // zeros shifted in from the top read as mismatches after the inversion
-                                const unsigned long long inv = ~(__ballot(eq) >> lane);
-                                run = inv ? (uint32_t)__builtin_ctzll(inv) : 64u;
-                                open = run == 64u - (uint32_t)lane;
-                            }
-                            // Beyond the item every match that is still open continues the same way:
-                            // one number, how far the data at p0 + 64 goes on matching at this
-                            // distance.  Four positions per lane and step: an aligned dword against
-                            // a dword shifted into place, first differing byte by find-first-set,
-                            // first differing lane by ballot.
-                            if (__ballot(open)) {
-                                uint32_t ext = 0;
-                                for (uint32_t st = 0; st < 2; ++st) {
-                                    const uint32_t q4 = p0 + 64u + (st << 8) + ((uint32_t)lane << 2);
-                                    const uint32_t a = *(const uint32_t *)(ring + (q4 & (RING - 1)));
-                                    const uint32_t s4 = q4 - d;
-                                    const uint32_t b0 = *(const uint32_t *)(ring + (s4 & (RING - 1) & ~3u));
-                                    const uint32_t b1 = *(const uint32_t *)(ring + ((s4 + 4u) & (RING - 1) & ~3u));
-                                    uint32_t x = a ^ __builtin_amdgcn_alignbyte(b1, b0, s4 & 3u);
-                                    // positions past the unit's end differ by decree
-                                    const uint32_t left = q4 < n ? n - q4 : 0u;
-                                    if (left < 4u) x |= left ? 0xffffffffu << (left << 3) : 0xffffffffu;
-                                    const unsigned long long mm = __ballot(x != 0u);
-                                    if (mm) {
-                                        const uint32_t fl_ = (uint32_t)__builtin_ctzll(mm);
-                                        ext += (fl_ << 2) + (rl(ffbl(x), fl_) >> 3);
-                                        break;
-                                    }
-                                    ext += 256u;
-                                }
-                                if (open) run += ext;
-                            }
-                            if (run > maxlen) run = maxlen;
-                            if (run >= 3 && d <= limit && (run > blen || (run == blen && d < best_dist))) {
-                                blen = run;
-                                best_dist = d;
-                            }
+                            score_distance(d);
                             todo &= ~__ballot(offer == d);
                         }
+                    }
+                    PH_END(13);
+                    // ---- long matches: a lane whose match is long and does not just continue its
+                    // predecessor's (same distance, one shorter) is where a parse may need something
+                    // better than the nearest long candidate.  The reference looks at every earlier
+                    // occurrence and keeps the longest (src/rawdeflate.js:370-395); two bounded
+                    // steps go after the same matches here.
+                    if ((P.deep > 0 || P.fan > 0) && __ballot(blen >= CMP_CAP && blen < maxlen)) {
+                        // exact length (up to 258) of the match of position px at distance d, px and d
+                        // uniform: four bytes per lane, first differing lane by ballot
+                        auto coop_len = [&](uint32_t px, uint32_t d, uint32_t mx) -> uint32_t {
+                            const uint32_t q4 = px + ((uint32_t)lane << 2), s4 = q4 - d;
+                            const uint32_t *wa = (const uint32_t *)(ring + (q4 & (RING - 1) & ~3u));
+                            const uint32_t *wb = (const uint32_t *)(ring + (s4 & (RING - 1) & ~3u));
+                            // the ring's mirror covers a dword pair that straddles its end
+                            uint32_t x = __builtin_amdgcn_alignbyte(wa[1], wa[0], q4 & 3u) ^
+                                         __builtin_amdgcn_alignbyte(wb[1], wb[0], s4 & 3u);
+                            const uint32_t off = (uint32_t)lane << 2;
+                            const uint32_t left = off < mx ? mx - off : 0u;
+                            if (left < 4u) x |= left ? 0xffffffffu << (left << 3) : 0xffffffffu;
+                            const unsigned long long mm = __ballot(x != 0u);
+                            if (mm) {
+                                const uint32_t fl_ = (uint32_t)__builtin_ctzll(mm);
+                                return (fl_ << 2) + (rl(ffbl(x), fl_) >> 3);
+                            }
+                            // 256 bytes agree; mx > 256 here: the last two (uniform addresses)
+                            uint32_t l = 256;
+                            while (l < mx && ring[(px + l) & (RING - 1)] == ring[(px + l - d) & (RING - 1)]) ++l;
+                            return l;
+                        };
+                        // the same for up to three distances at once (a zero distance is skipped)
+                        auto coop_len3 = [&](uint32_t px, const uint32_t (&ds)[3], uint32_t mx, uint32_t (&out)[3]) {
+                            const uint32_t q4 = px + ((uint32_t)lane << 2);
+                            const uint32_t *wa = (const uint32_t *)(ring + (q4 & (RING - 1) & ~3u));
+                            const uint32_t a = __builtin_amdgcn_alignbyte(wa[1], wa[0], q4 & 3u);
+                            uint32_t x[3];
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                const uint32_t s4 = q4 - ds[i];
+                                const uint32_t *wb = (const uint32_t *)(ring + (s4 & (RING - 1) & ~3u));
+                                x[i] = a ^ __builtin_amdgcn_alignbyte(wb[1], wb[0], s4 & 3u);
+                            }
+                            const uint32_t off = (uint32_t)lane << 2;
+                            const uint32_t left = off < mx ? mx - off : 0u;
+                            const uint32_t pad = left < 4u ? (left ? 0xffffffffu << (left << 3) : 0xffffffffu) : 0u;
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                out[i] = 0;
+                                if (!ds[i]) continue;  // uniform
+                                const uint32_t xi = x[i] | pad;
+                                const unsigned long long mm = __ballot(xi != 0u);
+                                if (mm) {
+                                    const uint32_t fl_ = (uint32_t)__builtin_ctzll(mm);
+                                    out[i] = (fl_ << 2) + (rl(ffbl(xi), fl_) >> 3);
+                                } else {
+                                    uint32_t l = 256;
+                                    while (l < mx && ring[(px + l) & (RING - 1)] == ring[(px + l - ds[i]) & (RING - 1)]) ++l;
+                                    out[i] = l;
+                                }
+                            }
+                        };
+                        const bool searchable = p + 4 <= n;
+                        auto starts = [&]() -> unsigned long long {
+                            const uint32_t pd = from_below(best_dist, 0u), pl = from_below(blen, 0u);
+                            return __ballot(searchable && blen >= CMP_CAP && blen < maxlen &&
+                                            !(pd == best_dist && pl == blen + 1u));
+                        };
+                        if (P.deep > 0) {
+                            // deep walk: the start lanes go on along their chains; a candidate is
+                            // looked at only if the byte after the current best agrees, and then
+                            // measured by the whole wave
+                            unsigned long long sm = starts();
+                            bool go = ((sm >> lane) & 1ull) && last != 0xffffu;
+                            if (__ballot(go)) {
+                                uint32_t tb = ring[(pi + blen) & (RING - 1)];
+                                uint32_t seq = 0;
+                                unsigned long long improved = 0;
+                                for (int budget = P.deep; budget > 0; --budget) {
+                                    const uint32_t dist = (p - c) & 0xffffu;
+                                    if (dist <= last || dist > limit) go = false;
+                                    // a chain that runs through consecutive positions is a run of one
+                                    // period: nothing longer further down
+                                    seq = dist == last + 1u ? seq + 1u : 0u;
+                                    if (seq >= 4u) go = false;
+                                    const unsigned long long gm = __ballot(go);
+                                    if (!gm) break;
+                                    bool hit = false;
+                                    if (go) {
+                                        last = dist;
+                                        const uint32_t cb = ring[(c + blen) & (RING - 1)];
+                                        c = prevt[c & WMASK];
+                                        hit = cb == tb;
+                                    }
+                                    unsigned long long hm = __ballot(hit);
+                                    while (hm) {
+                                        const uint32_t hl = (uint32_t)__builtin_ctzll(hm);
+                                        hm &= hm - 1ull;
+                                        const uint32_t px = p0 + hl, d = rl(last, hl), mx = rl(maxlen, hl);
+                                        const uint32_t len = coop_len(px, d, mx);
+                                        if ((uint32_t)lane == hl && len > blen) {
+                                            blen = len;
+                                            best_dist = d;
+                                            tb = ring[(pi + blen) & (RING - 1)];
+                                            if (len >= maxlen) go = false;
+                                            improved |= 1ull;
+                                        }
+                                    }
+                                }
+                                // what the walks found, for the lanes behind them
+                                const uint32_t offer = best_dist;
+                                unsigned long long todo = __ballot(improved != 0);
+                                for (int it = 0; it < 4 && todo; ++it) {
+                                    const uint32_t d = rl(offer, (uint32_t)__builtin_ctzll(todo));
+                                    score_distance(d);
+                                    todo &= ~__ballot(offer == d);
+                                }
+                            }
+                        }
+                        PH_END(2);
+                        // probe ahead: the positions after a start lane were linked to the nearest
+                        // earlier occurrence of their own four bytes; the distance of such a link,
+                        // tried at the start lane, is a candidate that agrees at least at that
+                        // later place -- the alignments that matter where repeats of different
+                        // lengths follow each other (runs, records)
+                        unsigned long long fanned = 0;
+                        for (int f = 0; f < P.fan; ++f) {
+                            // only where the match repeats at a short distance (a run, a short period): that
+                            // is where a longer match hides behind thousands of equally near candidates
+                            const unsigned long long sm = starts() & ~fanned & __ballot(best_dist <= FAN_MAXDIST);
+                            if (!sm) break;
+                            const uint32_t sl = (uint32_t)__builtin_ctzll(sm);
+                            fanned |= 1ull << sl;
+                            const uint32_t px = p0 + sl, cur = rl(blen, sl), mx = rl(maxlen, sl), lim = rl(limit, sl);
+                            const uint32_t own4 = rl(own.x, sl);
+                            // lane i probes the link of position px + j, j = cur - 3 + 4 i
+                            const uint32_t j = cur - 3u + ((uint32_t)lane << 2);
+                            const uint32_t q = px + j;
+                            bool ok = j + 4u <= mx;
+                            uint32_t d = 0;
+                            if (ok) {
+                                const uint32_t c2 = prevt[q & WMASK];
+                                d = (q - c2) & 0xffffu;
+                                ok = d >= 1u && d <= lim;
+                                if (ok) {
+                                    // the candidate agrees with px in its first four bytes, and the link
+                                    // is a real repeat of the four bytes at q (not a hash collision)
+                                    const uint32_t h4 = px - d, t4 = q - d;
+                                    const uint32_t *wh = (const uint32_t *)(ring + (h4 & (RING - 1) & ~3u));
+                                    const uint32_t *wt = (const uint32_t *)(ring + (t4 & (RING - 1) & ~3u));
+                                    const uint32_t *wq = (const uint32_t *)(ring + (q & (RING - 1) & ~3u));
+                                    const uint32_t vh = __builtin_amdgcn_alignbyte(wh[1], wh[0], h4 & 3u);
+                                    const uint32_t vt = __builtin_amdgcn_alignbyte(wt[1], wt[0], t4 & 3u);
+                                    const uint32_t vq = __builtin_amdgcn_alignbyte(wq[1], wq[0], q & 3u);
+                                    ok = vh == own4 && vt == vq;
+                                }
+                            }
+                            unsigned long long pm = __ballot(ok);
+                            // up to three distinct distances, the farthest probes first, measured
+                            // side by side (one LDS round trip)
+                            uint32_t dd[3] = {0u, 0u, 0u};
+#pragma unroll
+                            for (int tr = 0; tr < 3; ++tr)
+                                if (pm) {
+                                    dd[tr] = rl(d, 63u - (uint32_t)__builtin_clzll(pm));
+                                    pm &= ~__ballot(d == dd[tr]);
+                                }
+                            uint32_t nb = cur, nd = 0;
+                            if (dd[0]) {
+                                uint32_t ln[3];
+                                coop_len3(px, dd, mx, ln);
+#pragma unroll
+                                for (int tr = 0; tr < 3; ++tr)
+                                    if (dd[tr] && ln[tr] > nb) {
+                                        nb = ln[tr];
+                                        nd = dd[tr];
+                                    }
+                            }
+                            if (nd) score_distance(nd);
+                        }
+                        PH_END(3);
                     }
                     if (blen >= 3 && !(blen == 3 && best_dist > 4096)) best_len = blen;
                 }
@@ -1051,13 +1280,13 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         if (!__ballot(J < seg_end)) break;
                         // exit and count travel together: one permute per doubling step
                         const int src = (int)(J & 63u);
-                        const uint32_t t = (uint32_t)__shfl((int)(J | Cn << 16), src, 64);
+                        const uint32_t tt = (uint32_t)__shfl((int)(J | Cn << 16), src, 64);
                         const uint32_t tl = (uint32_t)__shfl((int)r_lo, src, 64), th = (uint32_t)__shfl((int)r_hi, src, 64);
                         const bool inb = J < seg_end;
-                        Cn += inb ? t >> 16 : 0u;
+                        Cn += inb ? tt >> 16 : 0u;
                         r_lo |= inb ? tl : 0u;
                         r_hi |= inb ? th : 0u;
-                        J = inb ? (t & 0xffffu) : J;
+                        J = inb ? (tt & 0xffffu) : J;
                     }
                     const uint32_t sl = k & (NSLOT - 1);
                     exit_tab[sl * 64 + lane] = (uint16_t)J;
@@ -1104,7 +1333,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
             PH_START();
             __syncthreads();
             PH_END(1);
-            if (tid == 0) misc[M_ITEM] = blk_end;  // the counter overshoots by one per wave
+            if (tid == 0) misc[M_ITEM] = blk_end + AHEAD;  // the counter overshoots by one per wave
             flush_block(blk);
             tokbuf += ZGPU_BLOCK_TOK;
             blk_first = blk_end;

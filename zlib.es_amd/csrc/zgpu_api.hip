@@ -21,6 +21,8 @@ thread_local int g_last_hip = 0;
 int g_max_chain = 8;
 int g_nice = 32;
 uint64_t g_split_bytes = 1ull << 20;  // units longer than twice this are cut into pieces of at most this size
+int g_deep = 0;        // long-match steps of the search kernel: deep-walk budget ...
+int g_fan = 1;         // ... and probe-ahead fans per item
 int g_min_lazy = 258;  // the parse always looks one position ahead unless told otherwise
 unsigned long long *g_prof = nullptr;  // diagnostic builds only
 
@@ -310,6 +312,13 @@ int zgpu_set_search(int max_chain, int nice_length) {
     return ZGPU_OK;
 }
 
+int zgpu_set_long_match(int deep_chain, int probe_fans) {
+    if (deep_chain < 0 || deep_chain > 32768 || probe_fans < 0 || probe_fans > 64) return ZGPU_E_ARG;
+    g_deep = deep_chain;
+    g_fan = probe_fans;
+    return ZGPU_OK;
+}
+
 int zgpu_set_split(uint64_t piece_bytes) {
     if (piece_bytes && piece_bytes < (1ull << 20)) return ZGPU_E_ARG;
     g_split_bytes = piece_bytes;
@@ -539,6 +548,8 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             P.lazy = p->lazy > g_min_lazy ? p->lazy : g_min_lazy;
             P.max_chain = g_max_chain;
             P.nice = g_nice;
+            P.deep = g_deep;
+            P.fan = g_fan;
             P.unit_prime = p->d_prime;
             P.prof = g_prof;
             const int sgrid = (int)(cnt < (uint32_t)p->ds->cus ? cnt : (uint32_t)p->ds->cus);
