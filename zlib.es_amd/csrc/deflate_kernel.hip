@@ -798,7 +798,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 const bool frontier_held = lds_ld(&misc[M_PARSE]) == k0 + NSLOT_E;
                 const uint32_t ldn = from_above(ld, 0u);  // the next position's match (lazy tokens)
                 uint32_t kind;
-                const uint32_t J = successor((ld >> 15) & 0x1ffu, (ldn >> 15) & 0x1ffu, kind);
+                (void)successor((ld >> 15) & 0x1ffu, (ldn >> 15) & 0x1ffu, kind);
                 const unsigned long long valid = seg_end == 64u ? ~0ull : ((1ull << seg_end) - 1ull);
                 const unsigned long long M = __ballot(kind != 0) & valid;
                 // the positions the parse visits in the item: the set that prep built for the
