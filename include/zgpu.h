@@ -194,6 +194,21 @@ int zgpu_plan_phase_ms(zgpu_plan *plan, float *search_ms, float *emit_ms);
 int zgpu_checksum(const uint8_t *in, uint64_t len, uint32_t *crc32, uint32_t *adler32);
 int zgpu_checksum_device(const void *d_in, uint64_t len, uint32_t *crc32, uint32_t *adler32,
                          void *stream);
+/* The device form for callers that cannot allocate or wait (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No
+ * counterpart in the reference.  Same result as zgpu_checksum_device, but the
+ * two values are written to DEVICE memory (d_out2[0] = CRC-32, d_out2[1] =
+ * Adler-32) by kernels enqueued on `stream`; the call returns after enqueueing
+ * and calls no hipMalloc / hipFree and no synchronisation.  Segment tables and
+ * per-segment results use a fixed array in the library's device image (about
+ * 86 KB per GPU, held until the process ends), so len is limited to
+ * zgpu_noalloc_max_bytes() (4 GiB; ZGPU_E_TOOBIG beyond) and calls that overlap
+ * on one GPU race on that array: run them on one stream or otherwise in order.
+ * The first call on a device uploads the lookup tables with one blocking copy;
+ * zgpu_noalloc_setup() (current device) does that ahead of time. */
+int zgpu_noalloc_setup(void);
+uint64_t zgpu_noalloc_max_bytes(void);
+int zgpu_checksum_device_noalloc(const void *d_in, uint64_t len, uint32_t *d_out2, void *stream);
 /* Resumable forms: CRC32.update(data, crc) (src/crc32.js:25) and
  * Adler32.update(adler, data) (src/adler32.js:20). */
 int zgpu_crc32_update(const uint8_t *in, uint64_t len, uint32_t crc, uint32_t *out);

@@ -23,7 +23,8 @@ SYMBOLS = [
     "zgpu_job_release", "zgpu_plan_create", "zgpu_plan_destroy",
     "zgpu_plan_out_bound", "zgpu_plan_run", "zgpu_plan_out_off_device", "zgpu_plan_crc_device",
     "zgpu_plan_adler_device", "zgpu_plan_fetch", "zgpu_plan_kernel_ms", "zgpu_plan_phase_ms", "zgpu_checksum",
-    "zgpu_checksum_device", "zgpu_crc32_update", "zgpu_adler32_update", "zgpu_checksum_kernel_ms",
+    "zgpu_checksum_device", "zgpu_noalloc_setup", "zgpu_noalloc_max_bytes",
+    "zgpu_checksum_device_noalloc", "zgpu_crc32_update", "zgpu_adler32_update", "zgpu_checksum_kernel_ms",
     "zgpu_crc32_combine", "zgpu_adler32_combine",
 ]
 
@@ -93,6 +94,12 @@ def lib():
     L.zgpu_checksum.argtypes = [vp, u64, C.POINTER(u32), C.POINTER(u32)]
     L.zgpu_checksum_device.restype = i32
     L.zgpu_checksum_device.argtypes = [vp, u64, C.POINTER(u32), C.POINTER(u32), vp]
+    L.zgpu_noalloc_setup.restype = i32
+    L.zgpu_noalloc_setup.argtypes = []
+    L.zgpu_noalloc_max_bytes.restype = u64
+    L.zgpu_noalloc_max_bytes.argtypes = []
+    L.zgpu_checksum_device_noalloc.restype = i32
+    L.zgpu_checksum_device_noalloc.argtypes = [vp, u64, vp, vp]
     L.zgpu_crc32_update.restype = i32
     L.zgpu_crc32_update.argtypes = [vp, u64, u32, C.POINTER(u32)]
     L.zgpu_adler32_update.restype = i32

@@ -238,6 +238,82 @@ struct zgpu_job {
     std::vector<uint32_t> crc, adler;
 };
 
+// ---- zgpu_checksum_device_noalloc: a checksum call that allocates nothing ------------------
+// Segment offsets, per-segment results and the lookup tables of zgpu_checksum_kernel live in one
+// file-scope device array, which every GPU holds from the moment the library is loaded.  In host
+// code the array's name is only a handle: its device address is asked for once per device
+// (hipGetSymbolAddress) and that pointer is what kernels and copies get.
+namespace {
+constexpr uint32_t kNaMaxSegs = 4096;                                  // 4 GiB in 1 MiB segments
+constexpr size_t kNaTables = 0;                                        // u32[20 * 256 + 8]
+constexpr size_t kNaSegOff = 21504;                                    // u64[kNaMaxSegs + 1]
+constexpr size_t kNaCrc = kNaSegOff + ((kNaMaxSegs + 1) * 8 + 255) / 256 * 256;  // u32[kNaMaxSegs]
+constexpr size_t kNaAdler = kNaCrc + kNaMaxSegs * 4;                   // u32[kNaMaxSegs]
+constexpr size_t kNaBytes = kNaAdler + kNaMaxSegs * 4;
+static_assert((20 * 256 + 8) * 4 <= kNaSegOff, "tables fit their slot");
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[kNaBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+unsigned char *g_na_ptr[kMaxDevices] = {};  // device address of `scratch`, per device, once set up
+std::mutex g_na_mu;
+}  // namespace
+
+// segment offsets 0, seg, 2 seg, ..., len
+extern "C" __global__ void __launch_bounds__(256)
+zgpu_na_offsets_kernel(uint64_t *seg_off, uint32_t n_segs, uint64_t seg, uint64_t len) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_segs) seg_off[i] = (uint64_t)i * seg;
+    if (i == n_segs) seg_off[i] = len;
+}
+
+// CRC-32 and Adler-32 of the whole buffer from the per-segment values.  Both combines are sums
+// over the segments: crc = xor_i crc_i * x^(8 * bytes after segment i) in GF(2)[x]/P, and
+// s1 = 1 + sum_i (s1_i - 1), s2 = sum_i s2_i + sum_i (s1_i - 1) * (bytes after segment i) mod 65521.
+extern "C" __global__ void __launch_bounds__(256)
+zgpu_na_fold_kernel(const uint64_t *seg_off, const uint32_t *seg_crc, const uint32_t *seg_adler, uint32_t n_segs,
+                    uint32_t *out2) {
+    __shared__ uint32_t r_crc[4];
+    __shared__ unsigned long long r_s1[4], r_s2[4];
+    const uint32_t M = 65521u;
+    const uint64_t len = seg_off[n_segs];
+    uint32_t crc = 0;
+    unsigned long long s1 = 0, s2 = 0;
+    for (uint32_t i = threadIdx.x; i < n_segs; i += 256) {
+        const uint64_t after = len - seg_off[i + 1];
+        // x^(8 * after) by square and multiply
+        uint32_t r = 0x80000000u, sq = 0x00800000u;
+        for (uint64_t e = after; e; e >>= 1) {
+            if (e & 1) r = gf_mul(r, sq);
+            sq = gf_mul(sq, sq);
+        }
+        crc ^= gf_mul(seg_crc[i], r);
+        const uint32_t a = seg_adler[i];
+        const unsigned long long d1 = ((a & 0xffffu) + M - 1) % M;
+        s1 += d1;
+        s2 += (a >> 16) + d1 * (after % M) % M;
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        crc ^= __shfl_down(crc, d, 64);
+        s1 += __shfl_down(s1, d, 64);
+        s2 += __shfl_down(s2, d, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        r_crc[wave] = crc;
+        r_s1[wave] = s1;
+        r_s2[wave] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out2[0] = r_crc[0] ^ r_crc[1] ^ r_crc[2] ^ r_crc[3];
+        const unsigned long long t1 = (1 + r_s1[0] + r_s1[1] + r_s1[2] + r_s1[3]) % M;
+        const unsigned long long t2 = (r_s2[0] + r_s2[1] + r_s2[2] + r_s2[3]) % M;
+        out2[1] = (uint32_t)(t2 << 16 | t1);
+    }
+}
+
 namespace {
 uint64_t unit_blocks(uint64_t n) { return n ? (n + ZGPU_BLOCK_BYTES - 1) / ZGPU_BLOCK_BYTES : 1; }
 // token slots (16 bits each) reserved for a unit: full blocks at their fixed stride, the last
@@ -821,6 +897,58 @@ int zgpu_checksum_device(const void *d_in, uint64_t len, uint32_t *crc32, uint32
     }
     if (crc32) *crc32 = crc;
     if (adler32) *adler32 = ad;
+    return ZGPU_OK;
+}
+
+int zgpu_noalloc_setup(void) {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return ZGPU_E_ARG;
+    std::lock_guard<std::mutex> lk(g_na_mu);
+    if (g_na_ptr[dev]) return ZGPU_OK;
+    unsigned char *ptr = nullptr;
+    HIPCHK(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+    std::vector<uint32_t> t;
+    build_tables(t);
+    HIPCHK(hipMemcpy(ptr + kNaTables, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    g_na_ptr[dev] = ptr;
+    return ZGPU_OK;
+}
+
+uint64_t zgpu_noalloc_max_bytes(void) { return (uint64_t)kNaMaxSegs * ZGPU_CK_SEG; }
+
+int zgpu_checksum_device_noalloc(const void *d_in, uint64_t len, uint32_t *d_out2, void *stream_) {
+    if (!d_out2 || (!d_in && len)) return ZGPU_E_ARG;
+    if (len > zgpu_noalloc_max_bytes()) return ZGPU_E_TOOBIG;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return ZGPU_E_ARG;
+    unsigned char *ptr;
+    {
+        std::lock_guard<std::mutex> lk(g_na_mu);
+        ptr = g_na_ptr[dev];
+    }
+    if (!ptr) {
+        // first call on this device: one blocking table upload (zgpu_noalloc_setup moves it
+        // out of, say, a stream capture)
+        int rc = zgpu_noalloc_setup();
+        if (rc) return rc;
+        std::lock_guard<std::mutex> lk(g_na_mu);
+        ptr = g_na_ptr[dev];
+    }
+    hipStream_t st = (hipStream_t)stream_;
+    const uint64_t seg = ZGPU_CK_SEG;
+    const uint32_t nseg = len ? (uint32_t)((len + seg - 1) / seg) : 1u;
+    uint64_t *seg_off = (uint64_t *)(ptr + kNaSegOff);
+    uint32_t *seg_crc = (uint32_t *)(ptr + kNaCrc), *seg_adler = (uint32_t *)(ptr + kNaAdler);
+    int cus = 0;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    hipLaunchKernelGGL(zgpu_na_offsets_kernel, dim3(nseg / 256 + 1), dim3(256), 0, st, seg_off, nseg, seg, len);
+    const uint32_t grid = nseg < (uint32_t)cus * 8u ? nseg : (uint32_t)cus * 8u;
+    hipLaunchKernelGGL(zgpu_checksum_kernel, dim3(grid), dim3(ZGPU_CK_THREADS), 0, st, (const uint8_t *)d_in,
+                       seg_off, nseg, (const uint32_t *)(ptr + kNaTables), seg_crc, seg_adler);
+    hipLaunchKernelGGL(zgpu_na_fold_kernel, dim3(1), dim3(256), 0, st, seg_off, seg_crc, seg_adler, nseg, d_out2);
+    HIPCHK(hipGetLastError());
     return ZGPU_OK;
 }
 
