@@ -15,10 +15,12 @@
  * ZGPU_E_NODEVICE.
  *
  * Threads: calls on different plans or jobs may run side by side, on one device
- * or several.  One plan serves one run at a time (run, fetch and the timing
- * queries of a plan are not to overlap), and the engine knobs (zgpu_set_*) and
- * zgpu_init / zgpu_shutdown are process-wide: set them while no call is in
- * flight.  zgpu_last_hip_error is per thread.
+ * or several (host-buffer calls that land on one device take turns).  One plan
+ * serves one run at a time (run, fetch and the timing queries of a plan are not
+ * to overlap).  The engine knobs (zgpu_set_*) are process-wide and are read
+ * once when a plan is created (a host-buffer call reads them when it starts):
+ * changing them never affects a plan that exists.  zgpu_last_hip_error is per
+ * thread.
  */
 #ifndef ZGPU_H
 #define ZGPU_H
@@ -61,19 +63,42 @@ enum {
     /* also compute per-unit CRC-32 / Adler-32 of the unit's INPUT
      * (CRC32.calc src/crc32.js:14, Adler32.mkHash src/adler32.js:11) */
     ZGPU_F_WANT_CRC = 16u,
-    ZGPU_F_WANT_ADLER = 32u
+    ZGPU_F_WANT_ADLER = 32u,
+    /* with ZGPU_F_PRIME_WINDOW: the batch continues a stream whose earlier part
+     * lies in `in` right before in_off[0] (up to 32 KiB are used, as many as
+     * in_off[0] allows), so the first unit's window is primed as well -- how a
+     * stream keeps its window when its chunks are shared by several calls,
+     * ranks or devices */
+    ZGPU_F_PRIME_FIRST = 64u
 };
 
 #define ZGPU_MAX_UNIT_BYTES (256u << 20)
 
 /* ---- library state ------------------------------------------------------ */
 /* Names the devices the host-buffer entry points may use (NULL/0 = whichever
- * device is current): a call made while another device is current runs on the
- * first one named and restores the caller's device.  Optional: every entry
- * point initialises lazily.  Device-pointer entry points (zgpu_plan_*,
- * zgpu_checksum_device) always use the current device. */
+ * device is current).  A host-buffer batch (zgpu_deflate_batch*) of 128 MiB and
+ * more is shared by the named devices: its units are split into contiguous
+ * ranges of about equal input bytes, one range per device (one more device per
+ * 64 MiB of input), every device runs its range through its own streams from
+ * its own host threads, and the host concatenates the results in unit order --
+ * no collective, the ranges are independent (what Zip.compress()'s per-file
+ * loop, src/zip.js:119-137, and the chunks of a long stream, src/gzip.js:107-111,
+ * allow).  Smaller calls run on the current device if it is among the named
+ * ones, else on the first named; the caller's current device is restored.
+ * Optional: every entry point initialises lazily.  Device-pointer entry points
+ * (zgpu_plan_*, zgpu_checksum_device*) always use the current device. */
 int zgpu_init(const int *device_ids, int n_devices);
+/* Releases the per-device state (tables, staging buffers, streams).  Does
+ * nothing while a plan or a job exists: destroy them first. */
 void zgpu_shutdown(void);
+/* The devices a host-buffer batch would use: writes up to cap ids, returns how
+ * many there are. */
+int zgpu_host_devices(int *device_ids, int cap);
+/* The split of a batch over n_parts devices: cut[d] .. cut[d + 1] are the units
+ * of part d (cut has n_parts + 1 entries; contiguous ranges, boundaries at the
+ * first unit that starts at or after d / n_parts of the input bytes).  Pure
+ * host arithmetic, no device needed. */
+int zgpu_partition_units(const uint64_t *in_off, uint32_t n_units, int n_parts, uint32_t *cut);
 const char *zgpu_strerror(int code);
 int zgpu_last_hip_error(void);
 /* Engine knobs (the reference searches every earlier occurrence,
@@ -128,7 +153,10 @@ uint64_t zgpu_deflate_bound(uint64_t in_len);
  * dynamicHuffman :243-259, BitStream src/bitstream.js:42-95) for n_units
  * independent inputs in one call; it is also what Zip.compress()'s per-file
  * loop (src/zip.js:119-137) turns into.  in/out are host pointers; the call
- * copies to the device, runs, copies back and blocks until done.
+ * blocks until done.  The batch moves in sub-batches of about 32 MiB through
+ * four stream slots per device, so uploads, kernels and downloads overlap;
+ * the slots' device buffers and workspaces are kept from call to call (a
+ * steady caller allocates nothing after its first calls).
  * out_off[i]..out_off[i+1] delimit unit i in out (contiguous).  crc32/adler32
  * may be NULL. */
 int zgpu_deflate_batch(const uint8_t *in, const uint64_t *in_off, uint32_t n_units,
@@ -168,12 +196,13 @@ uint64_t zgpu_plan_out_bound(const zgpu_plan *plan);
 int zgpu_plan_run(zgpu_plan *plan, const void *d_in, void *d_out, uint64_t out_cap, void *stream);
 /* Device-side results of the last run (valid once the stream has drained):
  * out_off: n_units+1 x uint64, crc/adler: n_units x uint32 (zero unless
- * requested), status: n_units x uint32 (0 = ok). */
+ * requested). */
 const uint64_t *zgpu_plan_out_off_device(const zgpu_plan *plan);
 const uint32_t *zgpu_plan_crc_device(const zgpu_plan *plan);
 const uint32_t *zgpu_plan_adler_device(const zgpu_plan *plan);
 /* Waits for the stream, copies results to host arrays (any may be NULL) and
- * returns ZGPU_E_UNIT if any unit reported overflow. */
+ * returns ZGPU_E_OUTCAP if d_out was too small for the compressed bytes, else
+ * ZGPU_E_UNIT if a unit overflowed its bounded slot. */
 int zgpu_plan_fetch(zgpu_plan *plan, uint64_t *out_off, uint32_t *crc32, uint32_t *adler32,
                     void *stream);
 /* Device time of the last run in milliseconds, measured with HIP events on the

@@ -20,19 +20,24 @@ def _free_port():
     return p
 
 
-def _oracle_fn(units, ctype, lazy, flags):
+HISTORIES = []  # what the sharder passed as history, per call (this process)
+
+
+def _oracle_fn(units, ctype, lazy, flags, history=None):
     # stands in for the GPU: complete streams per unit (FINAL_EACH) or stored-aligned chunks
+    HISTORIES.append(None if history is None else bytes(np.asarray(history, dtype=np.uint8)))
     outs, crcs, adlers = [], [], []
     for i, u in enumerate(units):
         u = np.asarray(u, dtype=np.uint8)
         raw = zo.rawdeflate(u, ctype, lazy)
         final = (flags & 1) or ((flags & 4) and i == len(units) - 1) or not (flags & 2)
         if not final:
-            # clear BFINAL of the (single) block and append an empty stored block
+            # a chunk that is followed by more of its stream: stored blocks are byte-aligned, so
+            # clearing BFINAL of the (single) block is all it takes
+            assert ctype == 0 and u.size <= 65535
             b = bytearray(raw)
             b[0] &= 0xFE
-            # the oracle pads the last byte with zero bits: three more zero bits + pad + 00 00 ff ff
-            raw = bytes(b) + b"\x00\x00\x00\xff\xff"
+            raw = bytes(b)
         outs.append(raw)
         crcs.append(zo.crc32(u))
         adlers.append(zo.adler32(u))
@@ -54,6 +59,20 @@ def _worker(rank, world, port, q):
             q.put(("units", ok, len(outs)))
         else:
             assert res is None
+        # chunks of one stream: gzip and zlib framing around the sharded body, and the bytes before a
+        # rank's first chunk handed over as history so that its window is primed across the boundary
+        d = zo.gen({"gen": "text", "n": 300_000, "seed": 77})
+        del HISTORIES[:]
+        gz = z.gzip_chunked(d, chunk_size=50_000, ctype=0, compress_fn=_oracle_fn)
+        zs = z.zlib_chunked(d, chunk_size=50_000, ctype=0, compress_fn=_oracle_fn)
+        if rank == 0:
+            assert HISTORIES == [None, None]
+            q.put(("streams", zo.gunzip(gz, d.size) == d.tobytes() and zo.inflate_zlib(zs, d.size) == d.tobytes()
+                   and zs[:2] == zo.zlib_compress(d, 0)[:2], 0))
+        else:
+            assert gz is None and zs is None
+            lo = z.partition_by_bytes([50_000] * 6, 2)[1][0]
+            assert HISTORIES == [d[lo * 50_000 - 32768:lo * 50_000].tobytes()] * 2
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -95,3 +114,21 @@ def test_two_rank_sharding_gloo():
         assert p.exitcode == 0
     kind, ok, n = q.get(timeout=10)
     assert kind == "units" and ok and n == 11
+    kind, ok, _ = q.get(timeout=10)
+    assert kind == "streams" and ok
+
+
+def test_c_partition_for_1_2_4_8_devices():
+    # the split zgpu_deflate_batch makes over the devices named by zgpu_init (host arithmetic)
+    import zlib_es_amd as z
+    rng = np.random.default_rng(1)
+    for sizes in ([65536] * 1024, rng.integers(1, 16385, 5000).tolist(), [0, 0, 7, 0, 100, 0], [5], [10] * 3):
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64) + np.uint64(12345)
+        total = int(off[-1] - off[0])
+        for parts in (1, 2, 4, 8):
+            cut = z._native.partition_units(off, parts)
+            assert cut[0] == 0 and cut[-1] == len(sizes) and all(a <= b for a, b in zip(cut, cut[1:]))
+            if len(sizes) >= 1024:
+                per = [int(off[b] - off[a]) for a, b in zip(cut, cut[1:])]
+                assert max(per) - min(per) <= 2 * max(sizes), (parts, per)
+                assert sum(per) == total

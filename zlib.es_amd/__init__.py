@@ -12,4 +12,4 @@ from . import _native  # noqa: F401
 from ._native import (DYNAMIC, FIXED, NONE, Plan, ZgpuError, adler32_combine,  # noqa: F401
                       checksum, crc32_combine, deflate_batch, deflate_bound, set_search)
 from .api import Adler32, CRC32, Deflate, Gzip, RawDeflate, Zip  # noqa: F401
-from .shard import combine_checksums, compress_sharded, gzip_chunked, partition_by_bytes  # noqa: F401
+from .shard import combine_checksums, compress_sharded, gzip_chunked, partition_by_bytes, zlib_chunked  # noqa: F401

@@ -13,11 +13,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZGPU_LIB") or os.path.join(_HERE, "libzgpu.so")
 
 NONE, FIXED, DYNAMIC = 0, 1, 2
-F_FINAL_EACH, F_SYNC_ALIGN, F_FINAL_LAST, F_PRIME_WINDOW, F_WANT_CRC, F_WANT_ADLER = 1, 2, 4, 8, 16, 32
+F_FINAL_EACH, F_SYNC_ALIGN, F_FINAL_LAST, F_PRIME_WINDOW, F_WANT_CRC, F_WANT_ADLER, F_PRIME_FIRST = 1, 2, 4, 8, 16, 32, 64
 
 # every symbol include/zgpu.h declares
 SYMBOLS = [
-    "zgpu_init", "zgpu_shutdown", "zgpu_strerror", "zgpu_last_hip_error", "zgpu_set_search", "zgpu_set_split",
+    "zgpu_init", "zgpu_shutdown", "zgpu_host_devices", "zgpu_partition_units", "zgpu_strerror", "zgpu_last_hip_error", "zgpu_set_search", "zgpu_set_split",
     "zgpu_set_min_lazy", "zgpu_set_long_match",
     "zgpu_deflate_bound", "zgpu_deflate_batch", "zgpu_deflate_batch_begin", "zgpu_deflate_batch_finish",
     "zgpu_job_release", "zgpu_plan_create", "zgpu_plan_destroy",
@@ -52,6 +52,10 @@ def lib():
     L.zgpu_init.restype = i32
     L.zgpu_init.argtypes = [C.POINTER(i32), i32]
     L.zgpu_shutdown.restype = None
+    L.zgpu_host_devices.restype = i32
+    L.zgpu_host_devices.argtypes = [vp, i32]
+    L.zgpu_partition_units.restype = i32
+    L.zgpu_partition_units.argtypes = [vp, u32, i32, vp]
     L.zgpu_strerror.restype = C.c_char_p
     L.zgpu_strerror.argtypes = [i32]
     L.zgpu_last_hip_error.restype = i32
@@ -154,6 +158,14 @@ def set_min_lazy(min_lazy):
     _check(lib().zgpu_set_min_lazy(min_lazy), "zgpu_set_min_lazy")
 
 
+def partition_units(in_off, n_parts):
+    """Unit ranges of a host batch over n_parts devices (host arithmetic, no GPU needed)."""
+    off = np.ascontiguousarray(in_off, dtype=np.uint64)
+    cut = np.zeros(n_parts + 1, dtype=np.uint32)
+    _check(lib().zgpu_partition_units(off.ctypes.data, off.size - 1, n_parts, cut.ctypes.data), "zgpu_partition_units")
+    return cut.tolist()
+
+
 def crc32_combine(a, b, len_b):
     return int(lib().zgpu_crc32_combine(a, b, len_b))
 
@@ -199,19 +211,27 @@ def checksum_kernel_ms():
     return ms.value
 
 
-def deflate_batch(units, ctype=DYNAMIC, lazy=0, flags=F_FINAL_EACH, want_crc=False, want_adler=False):
+def deflate_batch(units, ctype=DYNAMIC, lazy=0, flags=F_FINAL_EACH, want_crc=False, want_adler=False, history=None):
     """Compress a list of byte buffers in one GPU call (host buffers).
 
+    history: the bytes of the same stream that precede the first unit (chunked streams with
+    F_PRIME_WINDOW whose chunks are shared by several calls); up to 32 KiB of them are used.
     Returns (list of compressed bytes, crc32 list or None, adler32 list or None).
     """
     arrs = [_u8(u) for u in units]
     n = len(arrs)
     if n == 0:
         return [], ([] if want_crc else None), ([] if want_adler else None)
+    hist = _u8(history)[-32768:] if history is not None and len(history) else None
     off = np.zeros(n + 1, dtype=np.uint64)
     off[1:] = np.cumsum([a.size for a in arrs], dtype=np.uint64)
     total = int(off[-1])
-    flat = np.concatenate(arrs) if total else np.zeros(1, dtype=np.uint8)
+    if hist is not None:
+        off += np.uint64(hist.size)
+        flags |= F_PRIME_FIRST
+        flat = np.concatenate([hist] + arrs)
+    else:
+        flat = np.concatenate(arrs) if total else np.zeros(1, dtype=np.uint8)
     out_off = np.zeros(n + 1, dtype=np.uint64)
     crc = np.zeros(n, dtype=np.uint32) if want_crc else None
     adl = np.zeros(n, dtype=np.uint32) if want_adler else None

@@ -56,7 +56,7 @@ class CRC32:
         a = _as_u8(data)
         pos = 0 if pos is None else pos
         length = a.size if length is None else length  # the reference's `length` counts from pos
-        return N.crc32_update(a[pos:pos + length], crc & 0xFFFFFFFF)
+        return N.crc32_update(a[pos:pos + length], crc & 0xFFFFFFFF)  # the slice is clamped, and so is the combine
 
     @staticmethod
     def single(num, crc):
@@ -89,6 +89,7 @@ class RawDeflate:
 
     class CompressionType:
         NONE, FIXED, DYNAMIC, RESERVED = 0, 1, 2, 3
+        UNCOMPRESSED = 0  # the bundle's alias of NONE (src/zlib.es.js:111-117)
 
     def __init__(self, input, opt_params=None):
         self.compressionType = RawDeflate.CompressionType.DYNAMIC
@@ -112,7 +113,13 @@ class RawDeflate:
     # spy on them, test/browser.es/code-path-test.js:22-24) -------------------
     def _run(self, block, ctype, is_final):
         flags = N.F_FINAL_EACH if is_final else N.F_SYNC_ALIGN
-        out, _, _ = N.deflate_batch([block], ctype, self.lazy, flags)
+        # a container asks for the input's checksum with the same engine call (one upload)
+        want = getattr(self, "_want", 0)
+        out, crc, adler = N.deflate_batch([block], ctype, self.lazy, flags, want_crc=want == 1, want_adler=want == 2)
+        if want == 1:
+            self._crc32 = crc[0]
+        if want == 2:
+            self._adler32 = adler[0]
         head = self.output[: self.op]
         self.output = np.concatenate([head, np.frombuffer(out[0], dtype=np.uint8)])
         self.op = self.output.size
@@ -175,10 +182,11 @@ class Deflate:
         flg = self.compressionType << 6  # FLEVEL = compressionType (:62-71)
         flg |= 31 - ((cmf * 256 + flg) % 31)
         self.output[0], self.output[1] = cmf, flg
-        adler = Adler32.mkHash(self.input)  # :83
         self.rawDeflate.output = self.output
         self.rawDeflate.op = 2
+        self.rawDeflate._want = 2  # Adler-32 of the input (:83) from the same call
         body = self.rawDeflate.compress()  # :84-85
+        adler = self.rawDeflate._adler32
         trailer = np.array([(adler >> 24) & 0xFF, (adler >> 16) & 0xFF, (adler >> 8) & 0xFF, adler & 0xFF],
                            dtype=np.uint8)  # :94-97
         self.output = np.concatenate([body, trailer])
@@ -257,8 +265,9 @@ class Gzip:
         opts["outputBuffer"] = buf
         opts["outputIndex"] = len(hdr)
         rawdeflate = RawDeflate(self.input, opts)  # :107-111
+        rawdeflate._want = 1  # CRC-32 of the input (:117) from the same call
         body = rawdeflate.compress()
-        crc32 = CRC32.calc(self.input)  # :117
+        crc32 = rawdeflate._crc32
         il = self.input.size & 0xFFFFFFFF
         tr = np.array([crc32 & 0xFF, (crc32 >> 8) & 0xFF, (crc32 >> 16) & 0xFF, (crc32 >> 24) & 0xFF,
                        il & 0xFF, (il >> 8) & 0xFF, (il >> 16) & 0xFF, (il >> 24) & 0xFF], dtype=np.uint8)
@@ -349,8 +358,9 @@ class Zip:
                 raise NotImplementedError("ZipCrypto (src/zip.js:138-147,287-318) stays outside this engine")
             fl = len(opt["filename"]) if opt.get("filename") else 0
             cl = len(opt["comment"]) if opt.get("comment") else 0
-            local_size += 30 + fl + f["buffer"].size
-            central_size += 46 + fl + cl
+            xl = len(opt["extraField"]) if opt.get("extraField") else 0
+            local_size += 30 + fl + xl + f["buffer"].size
+            central_size += 46 + fl + xl + cl
         eocd = 22 + (len(self.comment) if self.comment else 0)
         out = np.zeros(local_size + central_size + eocd, dtype=np.uint8)
         op1, op2 = 0, local_size
@@ -364,6 +374,7 @@ class Zip:
             opt = f["option"]
             name = bytes(opt["filename"]) if opt.get("filename") else b""
             comment = bytes(opt["comment"]) if opt.get("comment") else b""
+            extra = bytes(opt["extraField"]) if opt.get("extraField") else b""  # :231-236
             offset = op1
             op1 = put(op1, Zip.LocalFileHeaderSignature)
             op2 = put(op2, Zip.FileHeaderSignature)
@@ -382,7 +393,7 @@ class Zip:
                       crc & 0xFF, (crc >> 8) & 0xFF, (crc >> 16) & 0xFF, (crc >> 24) & 0xFF,
                       size & 0xFF, (size >> 8) & 0xFF, (size >> 16) & 0xFF, (size >> 24) & 0xFF,
                       plain & 0xFF, (plain >> 8) & 0xFF, (plain >> 16) & 0xFF, (plain >> 24) & 0xFF,
-                      len(name) & 0xFF, (len(name) >> 8) & 0xFF, 0, 0]
+                      len(name) & 0xFF, (len(name) >> 8) & 0xFF, len(extra) & 0xFF, (len(extra) >> 8) & 0xFF]
             op1 = put(op1, common)
             op2 = put(op2, common)
             op2 = put(op2, [len(comment) & 0xFF, (len(comment) >> 8) & 0xFF, 0, 0, 0, 0, 0, 0, 0, 0,
@@ -390,6 +401,9 @@ class Zip:
             if name:
                 op1 = put(op1, np.frombuffer(name, dtype=np.uint8))
                 op2 = put(op2, np.frombuffer(name, dtype=np.uint8))
+            if extra:
+                op1 = put(op1, np.frombuffer(extra, dtype=np.uint8))
+                op2 = put(op2, np.frombuffer(extra, dtype=np.uint8))
             if comment:
                 op2 = put(op2, np.frombuffer(comment, dtype=np.uint8))
             op1 = put(op1, f["buffer"])

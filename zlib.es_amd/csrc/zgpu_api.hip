@@ -6,8 +6,12 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/zgpu.h"
@@ -18,12 +22,14 @@
 namespace {
 
 thread_local int g_last_hip = 0;
-int g_max_chain = 8;
-int g_nice = 32;
-uint64_t g_split_bytes = 1ull << 20;  // units longer than twice this are cut into pieces of at most this size
-int g_deep = 0;        // long-match steps of the search kernel: deep-walk budget ...
-int g_fan = 1;         // ... and probe-ahead fans per item
-int g_min_lazy = 258;  // the parse always looks one position ahead unless told otherwise
+// Engine knobs: process-wide, read once when a plan is set up (a plan keeps what it read).
+std::atomic<int> g_max_chain{8};
+std::atomic<int> g_nice{32};
+std::atomic<uint64_t> g_split_bytes{1ull << 20};  // units longer than twice this are cut into pieces of at most this size
+std::atomic<int> g_deep{0};        // long-match steps of the search kernel: deep-walk budget ...
+std::atomic<int> g_fan{1};         // ... and probe-ahead fans per item
+std::atomic<int> g_min_lazy{258};  // the parse always looks one position ahead unless told otherwise
+std::atomic<int> g_live{0};        // plans and jobs alive: zgpu_shutdown leaves the device state alone while any is
 unsigned long long *g_prof = nullptr;  // diagnostic builds only
 
 #define HIPCHK(expr)                         \
@@ -58,15 +64,18 @@ uint32_t h_xpow_bytes(uint64_t nbytes) {
     return r;
 }
 
+struct HostCtx;
+void free_host_ctx(HostCtx *c);
+struct CkScratch;  // segment tables of zgpu_checksum_device (defined with DevBuf below)
+void free_ck_scratch(CkScratch *c);
+
 struct DeviceState {
     int device = -1;
     int cus = 0;
     uint32_t *d_tables = nullptr;  // checksum kernel tables
     uint32_t *d_tables_wide = nullptr;  // 11-bit tables of the wide checksum kernel
-    // scratch for zgpu_checksum_device
-    uint64_t *d_seg_off = nullptr;
-    uint32_t *d_seg_crc = nullptr, *d_seg_adler = nullptr;
-    uint64_t seg_cap = 0;
+    CkScratch *ck = nullptr;       // scratch of zgpu_checksum_device
+    HostCtx *host = nullptr;       // staging of the host-buffer entry points
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ck_ms = 0.f;
     std::mutex ck_mu;  // zgpu_checksum_device calls on one device share the scratch above
@@ -119,9 +128,8 @@ void build_tables_wide(const std::vector<uint32_t> &t, std::vector<uint32_t> &w)
 void free_state(DeviceState *s) {
     (void)hipFree(s->d_tables);
     (void)hipFree(s->d_tables_wide);
-    (void)hipFree(s->d_seg_off);
-    (void)hipFree(s->d_seg_crc);
-    (void)hipFree(s->d_seg_adler);
+    free_ck_scratch(s->ck);
+    free_host_ctx(s->host);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
@@ -200,6 +208,60 @@ int get_state(DeviceState **out) {
 
 uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
+// A device buffer that only grows: the workspace of a plan and the staging of the host-buffer
+// entry points are kept from call to call, so a steady caller stops allocating.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return ZGPU_OK;
+        (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;  // headroom: batches of a steady caller vary a little
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            want = bytes;
+            e = hipMalloc(&p, want);
+        }
+        if (e != hipSuccess) {
+            g_last_hip = (int)e;
+            p = nullptr;
+            return e == hipErrorOutOfMemory ? ZGPU_E_NOMEM : ZGPU_E_NODEVICE;
+        }
+        cap = want;
+        return ZGPU_OK;
+    }
+    void release() {
+        (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T *as() const { return (T *)p; }
+};
+
+struct CkScratch {
+    DevBuf seg_off, seg_crc, seg_adler, out2;
+};
+void free_ck_scratch(CkScratch *c) {
+    if (!c) return;
+    c->seg_off.release();
+    c->seg_crc.release();
+    c->seg_adler.release();
+    c->out2.release();
+    delete c;
+}
+
+// the engine knobs as one plan sees them (read once, when the plan is set up)
+struct Knobs {
+    int max_chain, nice, deep, fan, min_lazy;
+    uint64_t split;
+};
+Knobs read_knobs() {
+    return Knobs{g_max_chain.load(), g_nice.load(), g_deep.load(), g_fan.load(), g_min_lazy.load(), g_split_bytes.load()};
+}
+
 }  // namespace
 
 struct zgpu_plan {
@@ -207,36 +269,449 @@ struct zgpu_plan {
     uint32_t n_units = 0;
     int ctype = 2, lazy = 0;
     uint32_t flags = 0;
+    Knobs knobs{};
     uint64_t in_total = 0, out_bound = 0, tmp_bytes = 0;
-    uint32_t n_pieces = 0;           // what the kernels see: units, the long ones cut into pieces
-    bool split = false;              // some unit has more than one piece
-    uint32_t *d_prime = nullptr;     // per piece: bytes before it that prime its window
-    uint8_t *d_final = nullptr;      // per piece: ends its stream
-    uint64_t *d_unit_in_off = nullptr, *d_unit_out_off = nullptr;  // per unit (only when split)
-    uint32_t *d_first_piece = nullptr;
-    std::vector<uint32_t> first_piece;
-    uint64_t *d_in_off = nullptr, *d_slot_off = nullptr, *d_out_off = nullptr;
-    uint32_t *d_out_size = nullptr, *d_status = nullptr, *d_crc = nullptr, *d_adler = nullptr;
-    uint16_t *d_tok = nullptr;       // token slots of one round
-    uint32_t *d_counter = nullptr;
-    uint64_t *d_tok_off = nullptr;   // per unit: first token within its round's buffer
-    uint32_t *d_blk_first = nullptr; // per unit: index of its first block
-    uint32_t *d_hist = nullptr, *d_ntok = nullptr;  // per block
-    uint8_t *d_out_tmp = nullptr;
+    uint32_t n_pieces = 0;  // what the kernels see: units, the long ones cut into pieces
+    bool split = false;     // some unit has more than one piece
+    // Unit tables: built on the host into one blob, uploaded with one copy.  The pointers below
+    // point into d_tab.
+    std::vector<uint8_t> h_tab;
+    DevBuf d_tab;
+    uint64_t *d_in_off = nullptr, *d_slot_off = nullptr, *d_tok_off = nullptr, *d_unit_in_off = nullptr;
+    uint32_t *d_blk_first = nullptr, *d_prime = nullptr, *d_first_piece = nullptr;
+    uint8_t *d_final = nullptr;
+    // results and workspace
+    DevBuf b_out_off, b_unit_out_off, b_out_size, b_status, b_crc, b_adler, b_counter, b_tok, b_hist, b_ntok, b_out_tmp;
+    uint64_t *d_out_off() const { return b_out_off.as<uint64_t>(); }
+    uint64_t *d_unit_out_off() const { return b_unit_out_off.as<uint64_t>(); }
+    uint32_t *d_out_size() const { return b_out_size.as<uint32_t>(); }
+    uint32_t *d_status() const { return b_status.as<uint32_t>(); }
+    uint32_t *d_crc() const { return b_crc.as<uint32_t>(); }
+    uint32_t *d_adler() const { return b_adler.as<uint32_t>(); }
+    uint32_t *d_counter() const { return b_counter.as<uint32_t>(); }
     struct Round { uint32_t first, end; };
-    std::vector<Round> rounds;       // units whose tokens share the token buffer at one time
+    std::vector<Round> rounds;  // units whose tokens share the token buffer at one time
+    std::vector<uint32_t> h_status;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ran = false;
+    bool pooled = false;  // owned by a device's host context (not counted as a caller's live plan)
+    void release_buffers() {
+        for (DevBuf *b : {&d_tab, &b_out_off, &b_unit_out_off, &b_out_size, &b_status, &b_crc, &b_adler, &b_counter, &b_tok,
+                          &b_hist, &b_ntok, &b_out_tmp})
+            b->release();
+    }
 };
 
-// a host-buffer batch between its two calls: results fetched, compressed bytes still on the device
-struct zgpu_job {
-    int device = -1;
+namespace {
+uint64_t unit_blocks(uint64_t n) { return n ? (n + ZGPU_BLOCK_BYTES - 1) / ZGPU_BLOCK_BYTES : 1; }
+// token slots (16 bits each) reserved for a unit: full blocks at their fixed stride, the last
+// one exact, rounded so that every region starts on 8 bytes and reads of four slots stay inside
+uint64_t unit_tok_cap(uint64_t n) {
+    const uint64_t nb = unit_blocks(n), last = n - (nb - 1) * ZGPU_BLOCK_BYTES;
+    return (nb - 1) * ZGPU_BLOCK_TOK + ((last + 1 + 3) & ~3ull) + 4;
+}
+
+// (Re)targets a plan at a unit table: builds the piece / slot / token tables, grows the
+// workspace where it is too small and uploads the tables on `st`.  history: bytes of the same
+// stream that lie in the input buffer right before in_off[0] (they prime the first unit's window
+// when the batch is a chunked stream with ZGPU_F_PRIME_WINDOW).
+int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype, int lazy, uint32_t flags,
+               uint64_t history, hipStream_t st, bool async) {
+    if (!in_off || n_units == 0) return ZGPU_E_ARG;
+    if (ctype < 0 || ctype > 2 || lazy < 0) return ZGPU_E_ARG;
+    for (uint32_t i = 0; i < n_units; ++i) {
+        if (in_off[i + 1] < in_off[i]) return ZGPU_E_ARG;
+        if (in_off[i + 1] - in_off[i] > ZGPU_MAX_UNIT_BYTES) return ZGPU_E_TOOBIG;
+    }
+    DeviceState *ds = p->ds;
+    p->n_units = n_units;
+    p->ctype = ctype;
+    p->lazy = lazy;
+    p->flags = flags;
+    p->knobs = read_knobs();
+    p->in_total = in_off[n_units];
+    p->ran = false;
+    p->rounds.clear();
+    // ---- pieces: what the kernels work on.  A unit longer than twice the split size is cut
+    // into pieces of that size, each compressed by its own workgroup as a chunk of the unit's
+    // stream: byte-aligned end (empty stored block), window primed with the 32 KiB before it.
+    // A unit's pieces are consecutive, so its output is their concatenation.
+    const bool chunked = (flags & ZGPU_F_SYNC_ALIGN) && !(flags & ZGPU_F_FINAL_EACH);
+    const bool prime_units = chunked && (flags & ZGPU_F_PRIME_WINDOW);
+    // Piece size: a batch with fewer units than kPiecesPerCu per CU (the unit queue then balances
+    // poorly at its tail, and the emit kernel's workgroups run short) cuts units longer than two
+    // pieces into pieces of total / (kPiecesPerCu x CUs) bytes, between 128 KiB and the set limit.
+    constexpr uint32_t kPiecesPerCu = 16;
+    uint64_t piece = 0;
+    if (ctype != ZGPU_NONE && p->knobs.split && n_units < kPiecesPerCu * (uint32_t)ds->cus) {
+        piece = align_up((in_off[n_units] - in_off[0]) / ((uint64_t)kPiecesPerCu * (uint64_t)ds->cus) + 1, 65536);
+        if (piece < (128u << 10)) piece = 128u << 10;
+        if (piece > p->knobs.split) piece = p->knobs.split;
+    }
+    std::vector<uint64_t> pc_off;       // piece offsets into the input, n_pieces + 1
+    std::vector<uint32_t> first_piece;  // per unit, n_units + 1
+    std::vector<uint32_t> pc_prime;     // bytes of the same stream before the piece that prime its window
+    std::vector<uint8_t> pc_final;      // piece ends its stream (BFINAL) / ends with an empty stored block
+    for (uint32_t i = 0; i < n_units; ++i) {
+        const uint64_t o = in_off[i], n = in_off[i + 1] - o;
+        const uint64_t split = (piece && n > 2 * piece) ? piece : 0;
+        const uint64_t np = split ? (n + split - 1) / split : 1;
+        const bool unit_final = !chunked || ((flags & ZGPU_F_FINAL_LAST) && i == n_units - 1);
+        first_piece.push_back((uint32_t)pc_off.size());
+        for (uint64_t k = 0; k < np; ++k) {
+            pc_off.push_back(o + k * split);
+            uint64_t before = k ? k * split : (prime_units ? o - in_off[0] + history : 0);
+            if (before > 32768) before = 32768;
+            pc_prime.push_back((uint32_t)before & ~63u);
+            pc_final.push_back(unit_final && k == np - 1);
+        }
+        if (pc_off.size() > 0x7fffffffull) return ZGPU_E_TOOBIG;
+    }
+    const uint32_t n_pieces = (uint32_t)pc_off.size();
+    first_piece.push_back(n_pieces);
+    pc_off.push_back(in_off[n_units]);
+    p->n_pieces = n_pieces;
+    p->split = n_pieces != n_units;
+    std::vector<uint64_t> slot(n_pieces + 1);
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < n_pieces; ++i) {
+        slot[i] = acc;
+        acc += align_up(zgpu_deflate_bound(pc_off[i + 1] - pc_off[i]) + 32, 16);
+    }
+    slot[n_pieces] = acc;
+    p->tmp_bytes = acc;
+    p->out_bound = acc;
+    // Token scratch: 2 bytes per input byte in the worst case.  Pieces are cut into rounds
+    // whose tokens fit a buffer of at most a third of the free device memory (ZGPU_TOK_BYTES
+    // overrides; never less than one maximum-size piece needs).
+    std::vector<uint64_t> tok_off(n_pieces);
+    std::vector<uint32_t> blk_first(n_pieces);
+    uint64_t tok_buf_tokens = 0, n_blocks = 0;
+    if (ctype != ZGPU_NONE) {
+        size_t free_b = 0, total_b = 0;
+        uint64_t cap_bytes = 8ull << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap_bytes = (free_b + p->b_tok.cap) / 3;
+        if (const char *e = getenv("ZGPU_TOK_BYTES")) cap_bytes = strtoull(e, nullptr, 10);
+        const uint64_t cap_tokens = cap_bytes / 2;
+        uint64_t used = 0;
+        uint32_t first = 0;
+        for (uint32_t i = 0; i < n_pieces; ++i) {
+            const uint64_t n = pc_off[i + 1] - pc_off[i], need = unit_tok_cap(n);
+            if (used && used + need > cap_tokens) {
+                p->rounds.push_back({first, i});
+                first = i;
+                used = 0;
+            }
+            tok_off[i] = used;
+            used += need;
+            if (used > tok_buf_tokens) tok_buf_tokens = used;
+            if (n_blocks + unit_blocks(n) > 0xffffffffull) return ZGPU_E_TOOBIG;
+            blk_first[i] = (uint32_t)n_blocks;
+            n_blocks += unit_blocks(n);
+        }
+        p->rounds.push_back({first, n_pieces});
+    }
+    // ---- one blob for the tables the kernels read ----
+    size_t off = 0;
+    auto place = [&](size_t bytes) {
+        const size_t at = off;
+        off = align_up(off + bytes, 16);
+        return at;
+    };
+    const size_t o_in = place((size_t)(n_pieces + 1) * 8), o_slot = place((size_t)(n_pieces + 1) * 8),
+                 o_tok = place((size_t)n_pieces * 8), o_blk = place((size_t)n_pieces * 4),
+                 o_prime = place((size_t)n_pieces * 4), o_final = place((size_t)n_pieces),
+                 o_uin = place(p->split ? (size_t)(n_units + 1) * 8 : 0),
+                 o_fp = place(p->split ? (size_t)(n_units + 1) * 4 : 0);
+    p->h_tab.resize(off);
+    uint8_t *h = p->h_tab.data();
+    memcpy(h + o_in, pc_off.data(), (size_t)(n_pieces + 1) * 8);
+    memcpy(h + o_slot, slot.data(), (size_t)(n_pieces + 1) * 8);
+    memcpy(h + o_tok, tok_off.data(), (size_t)n_pieces * 8);
+    memcpy(h + o_blk, blk_first.data(), (size_t)n_pieces * 4);
+    memcpy(h + o_prime, pc_prime.data(), (size_t)n_pieces * 4);
+    memcpy(h + o_final, pc_final.data(), (size_t)n_pieces);
+    if (p->split) {
+        memcpy(h + o_uin, in_off, (size_t)(n_units + 1) * 8);
+        memcpy(h + o_fp, first_piece.data(), (size_t)(n_units + 1) * 4);
+    }
+    int rc;
+#define ENS(buf, bytes)                        \
+    if ((rc = (buf).ensure(bytes)) != ZGPU_OK) return rc
+    ENS(p->d_tab, off);
+    ENS(p->b_out_off, (size_t)(n_pieces + 1) * 8);
+    ENS(p->b_out_size, (size_t)n_pieces * 4);
+    ENS(p->b_status, (size_t)n_pieces * 4);
+    ENS(p->b_crc, (size_t)n_units * 4);
+    ENS(p->b_adler, (size_t)n_units * 4);
+    ENS(p->b_counter, (p->rounds.size() * 2 + 2) * 4);
+    ENS(p->b_out_tmp, p->tmp_bytes + 64);
+    if (ctype != ZGPU_NONE) {
+        ENS(p->b_tok, (size_t)tok_buf_tokens * 2 + 64);
+        ENS(p->b_hist, (size_t)n_blocks * 320 * 4);
+        ENS(p->b_ntok, (size_t)n_blocks * 4);
+    }
+    if (p->split) ENS(p->b_unit_out_off, (size_t)(n_units + 1) * 8);
+#undef ENS
+    uint8_t *d = p->d_tab.as<uint8_t>();
+    p->d_in_off = (uint64_t *)(d + o_in);
+    p->d_slot_off = (uint64_t *)(d + o_slot);
+    p->d_tok_off = (uint64_t *)(d + o_tok);
+    p->d_blk_first = (uint32_t *)(d + o_blk);
+    p->d_prime = (uint32_t *)(d + o_prime);
+    p->d_final = d + o_final;
+    p->d_unit_in_off = (uint64_t *)(d + o_uin);
+    p->d_first_piece = (uint32_t *)(d + o_fp);
+    if (async) {
+        // pageable source: the runtime has taken the bytes when the call returns
+        HIPCHK(hipMemcpyAsync(d, h, off, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(p->b_crc.p, 0, (size_t)n_units * 4, st));
+        HIPCHK(hipMemsetAsync(p->b_adler.p, 0, (size_t)n_units * 4, st));
+    } else {
+        HIPCHK(hipMemcpy(d, h, off, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(p->b_crc.p, 0, (size_t)n_units * 4));
+        HIPCHK(hipMemset(p->b_adler.p, 0, (size_t)n_units * 4));
+    }
+    for (int i = 0; i < 5; ++i)
+        if (!p->ev[i]) HIPCHK(hipEventCreate(&p->ev[i]));
+    return ZGPU_OK;
+}
+
+// ---- host-buffer entry points: per-device staging kept from call to call ----------------
+// A batch in host memory is cut into sub-batches of about kSubBytes of input (32 MiB).  Four slots per
+// device (stream, input buffer, plan with its workspace) take them in turn, each driven by its
+// own host thread: the upload of one sub-batch runs while another is compressed and a third is
+// fetched, so PCIe and the kernels overlap.  Nothing here is allocated per call once the
+// buffers have grown to the caller's batch size.
+constexpr int kMaxSlots = 8;
+// tuning overrides (read once): ZGPU_SUB_BYTES, ZGPU_SLOTS
+const uint64_t kSubBytes = [] {
+    const char *e = getenv("ZGPU_SUB_BYTES");
+    const uint64_t v = e ? strtoull(e, nullptr, 10) : 0;
+    return v >= (1ull << 20) ? v : (32ull << 20);
+}();
+const int kSlots = [] {
+    const char *e = getenv("ZGPU_SLOTS");
+    const int v = e ? atoi(e) : 0;
+    return v >= 2 && v <= kMaxSlots ? v : 4;
+}();
+struct Slot {
+    hipStream_t st = nullptr;
+    DevBuf d_in;
     zgpu_plan *plan = nullptr;
-    uint8_t *d_in = nullptr, *d_out = nullptr;
-    std::vector<uint64_t> out_off;
-    std::vector<uint32_t> crc, adler;
+    DevBuf ck_off, ck_crc, ck_adler;  // segment tables of the host checksum call
 };
+struct HostCtx {
+    std::mutex mu;  // one host-buffer call at a time per device
+    Slot slot[kMaxSlots];
+    DevBuf d_res;  // compressed bytes of a batch until they are copied out (spare; a job takes it)
+    DevBuf ck_res;
+};
+
+void free_host_ctx(HostCtx *c) {
+    if (!c) return;
+    for (Slot &s : c->slot) {
+        if (s.plan) zgpu_plan_destroy(s.plan);
+        s.d_in.release();
+        s.ck_off.release();
+        s.ck_crc.release();
+        s.ck_adler.release();
+        if (s.st) (void)hipStreamDestroy(s.st);
+    }
+    c->d_res.release();
+    c->ck_res.release();
+    delete c;
+}
+
+// the context of the current device (created on first use)
+int get_host_ctx(DeviceState *ds, HostCtx **out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!ds->host) {
+        auto *c = new (std::nothrow) HostCtx();
+        if (!c) return ZGPU_E_NOMEM;
+        for (int si = 0; si < kSlots; ++si) {
+            Slot &s = c->slot[si];
+            hipError_t e = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking);
+            if (e == hipSuccess) {
+                s.plan = new (std::nothrow) zgpu_plan();
+                if (s.plan) {
+                    s.plan->ds = ds;
+                    s.plan->pooled = true;
+                }
+            }
+            if (e != hipSuccess || !s.plan) {
+                g_last_hip = (int)e;
+                free_host_ctx(c);
+                return e != hipSuccess ? ZGPU_E_NODEVICE : ZGPU_E_NOMEM;
+            }
+        }
+        ds->host = c;
+    }
+    *out = ds->host;
+    return ZGPU_OK;
+}
+
+// Contiguous ranges of units for n_dev devices, balanced by input bytes: range d ends at the
+// first unit boundary at or after d + 1 parts of the total (units are never cut here).
+void split_units_by_bytes(const uint64_t *in_off, uint32_t n_units, int n_dev, std::vector<uint32_t> &cut) {
+    cut.assign((size_t)n_dev + 1, n_units);
+    cut[0] = 0;
+    const uint64_t base = in_off[0], total = in_off[n_units] - base;
+    uint32_t u = 0;
+    for (int d = 1; d < n_dev; ++d) {
+        const uint64_t want = base + (total / (uint64_t)n_dev) * (uint64_t)d + (total % (uint64_t)n_dev) * (uint64_t)d / (uint64_t)n_dev;
+        while (u < n_units && in_off[u] < want) ++u;
+        cut[d] = u;
+    }
+}
+
+struct SubBatch {
+    uint32_t first = 0, end = 0;  // units
+    int dev_index = 0;            // which of the job's devices
+    uint64_t res_off = 0;         // where its compressed bytes start in that device's result buffer
+    uint64_t res_cap = 0;         // and how many that region holds
+    uint64_t out_bytes = 0;       // their size, once compressed
+};
+}  // namespace
+
+// a host-buffer batch between its two calls: sizes known, compressed bytes still on the device(s)
+struct zgpu_job {
+    struct Dev {
+        int device = -1;
+        DeviceState *ds = nullptr;
+        HostCtx *ctx = nullptr;
+        DevBuf d_res;
+        uint64_t res_need = 0;
+    };
+    std::vector<Dev> devs;
+    std::vector<SubBatch> subs;
+    std::vector<uint64_t> out_off;  // per unit, n + 1
+    std::vector<uint32_t> crc, adler;
+    uint32_t n_units = 0;
+};
+
+namespace {
+
+// compresses sub-batch `sb` of the job on slot `sl` of its device; when out != null and the
+// sub-batches before it are placed, also copies its bytes to their final place in out
+struct BatchShared {
+    const uint8_t *in;
+    const uint64_t *in_off;
+    uint32_t n_units;
+    int ctype, lazy;
+    uint32_t flags;
+    zgpu_job *job;
+    // ordered placement (one device, caller's buffer known): sub-batch i may copy out once the
+    // sizes of all sub-batches before it are known
+    uint8_t *out = nullptr;
+    uint64_t out_cap = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t placed = 0;       // sub-batches [0, placed) have their sizes in
+    uint64_t placed_bytes = 0;
+    int rc = ZGPU_OK;        // first error
+};
+
+int run_sub(BatchShared &S, size_t si, Slot &sl) {
+    zgpu_job *j = S.job;
+    SubBatch &sb = j->subs[si];
+    zgpu_job::Dev &dv = j->devs[sb.dev_index];
+    const uint32_t n = sb.end - sb.first;
+    const uint64_t *go = S.in_off + sb.first;
+    const bool chunked = (S.flags & ZGPU_F_SYNC_ALIGN) && !(S.flags & ZGPU_F_FINAL_EACH);
+    // bytes of the same stream right before the sub-batch's first unit travel with it
+    uint64_t hist = 0;
+    if (chunked && (S.flags & ZGPU_F_PRIME_WINDOW)) {
+        hist = go[0] - S.in_off[0];
+        if (S.flags & ZGPU_F_PRIME_FIRST) hist = go[0];  // the stream began before the batch
+        if (hist > 32768) hist = 32768;
+    }
+    const uint64_t lo = go[0] - hist, hi = go[n];
+    const uint64_t lead = lo & 255u;  // the kernels see the caller's alignment (modulo 256)
+    // unit offsets relative to the slot's input buffer
+    std::vector<uint64_t> rel((size_t)n + 1);
+    for (uint32_t i = 0; i <= n; ++i) rel[i] = go[i] - lo + lead;
+    uint32_t flags = S.flags;
+    if (sb.end != S.n_units) flags &= ~(uint32_t)ZGPU_F_FINAL_LAST;
+    int rc = plan_setup(sl.plan, rel.data(), n, S.ctype, S.lazy, flags, hist, sl.st, true);
+    if (rc) return rc;
+    if ((rc = sl.d_in.ensure(lead + (hi - lo) + 64)) != ZGPU_OK) return rc;
+    if (hi > lo) HIPCHK(hipMemcpyAsync(sl.d_in.as<uint8_t>() + lead, S.in + lo, hi - lo, hipMemcpyHostToDevice, sl.st));
+    uint8_t *d_out = dv.d_res.as<uint8_t>() + sb.res_off;
+    rc = zgpu_plan_run(sl.plan, sl.d_in.p, d_out, sb.res_cap, sl.st);
+    if (rc) return rc;
+    // offsets relative to this sub-batch's result region; the n + 1 entries go through a local
+    // array because entry n would land on the next sub-batch's first
+    std::vector<uint64_t> loc((size_t)n + 1);
+    rc = zgpu_plan_fetch(sl.plan, loc.data(), j->crc.empty() ? nullptr : j->crc.data() + sb.first,
+                         j->adler.empty() ? nullptr : j->adler.data() + sb.first, sl.st);
+    if (rc) return rc;
+    memcpy(j->out_off.data() + sb.first, loc.data(), (size_t)n * sizeof(uint64_t));
+    sb.out_bytes = loc[n];
+    if (!S.out) return ZGPU_OK;
+    uint64_t at;
+    {
+        std::unique_lock<std::mutex> lk(S.mu);
+        S.cv.wait(lk, [&] { return S.placed == si || S.rc != ZGPU_OK; });
+        if (S.rc != ZGPU_OK) return ZGPU_OK;  // someone else failed; that error is reported
+        at = S.placed_bytes;
+        S.placed_bytes += sb.out_bytes;
+        S.placed = si + 1;
+    }
+    S.cv.notify_all();
+    if (at + sb.out_bytes > S.out_cap) return ZGPU_E_OUTCAP;
+    if (sb.out_bytes) {
+        HIPCHK(hipMemcpyAsync(S.out + at, d_out, sb.out_bytes, hipMemcpyDeviceToHost, sl.st));
+        HIPCHK(hipStreamSynchronize(sl.st));
+    }
+    return ZGPU_OK;
+}
+
+void fail_shared(BatchShared &S, int rc) {
+    {
+        std::lock_guard<std::mutex> lk(S.mu);
+        if (S.rc == ZGPU_OK) S.rc = rc;
+    }
+    S.cv.notify_all();
+}
+
+// all sub-batches of one device, slot threads side by side
+void run_device(BatchShared &S, int dev_index) {
+    zgpu_job::Dev &dv = S.job->devs[dev_index];
+    std::vector<size_t> mine;
+    for (size_t i = 0; i < S.job->subs.size(); ++i)
+        if (S.job->subs[i].dev_index == dev_index) mine.push_back(i);
+    if (mine.empty()) return;
+    std::lock_guard<std::mutex> ctx_lock(dv.ctx->mu);
+    auto worker = [&](int slot) {
+        if (hipSetDevice(dv.device) != hipSuccess) {
+            fail_shared(S, ZGPU_E_NODEVICE);
+            return;
+        }
+        for (size_t k = (size_t)slot; k < mine.size(); k += kSlots) {
+            {
+                std::lock_guard<std::mutex> lk(S.mu);
+                if (S.rc != ZGPU_OK) return;
+            }
+            const int rc = run_sub(S, mine[k], dv.ctx->slot[slot]);
+            if (rc) {
+                fail_shared(S, rc);
+                return;
+            }
+        }
+    };
+    if (mine.size() == 1) {
+        worker(0);  // the latency path: no thread is started for a small call
+        return;
+    }
+    std::vector<std::thread> th;
+    const int nth = (int)(mine.size() < (size_t)kSlots ? mine.size() : (size_t)kSlots);
+    for (int s = 1; s < nth; ++s) th.emplace_back(worker, s);
+    worker(0);
+    for (auto &t : th) t.join();
+}
+
+}  // namespace
 
 // ---- zgpu_checksum_device_noalloc: a checksum call that allocates nothing ------------------
 // Segment offsets, per-segment results and the lookup tables of zgpu_checksum_kernel live in one
@@ -314,16 +789,6 @@ zgpu_na_fold_kernel(const uint64_t *seg_off, const uint32_t *seg_crc, const uint
     }
 }
 
-namespace {
-uint64_t unit_blocks(uint64_t n) { return n ? (n + ZGPU_BLOCK_BYTES - 1) / ZGPU_BLOCK_BYTES : 1; }
-// token slots (16 bits each) reserved for a unit: full blocks at their fixed stride, the last
-// one exact, rounded so that every region starts on 8 bytes and reads of four slots stay inside
-uint64_t unit_tok_cap(uint64_t n) {
-    const uint64_t nb = unit_blocks(n), last = n - (nb - 1) * ZGPU_BLOCK_BYTES;
-    return (nb - 1) * ZGPU_BLOCK_TOK + ((last + 1 + 3) & ~3ull) + 4;
-}
-}  // namespace
-
 extern "C" {
 
 int zgpu_init(const int *device_ids, int n_devices) {
@@ -340,6 +805,7 @@ int zgpu_init(const int *device_ids, int n_devices) {
 }
 
 void zgpu_shutdown(void) {
+    if (g_live.load() > 0) return;  // plans or jobs still hold device state: destroy them first
     std::lock_guard<std::mutex> lk(g_mu);
     int cur = 0;
     (void)hipGetDevice(&cur);
@@ -416,7 +882,7 @@ int zgpu_plan_create(zgpu_plan **out, const uint64_t *in_off, uint32_t n_units, 
                      uint32_t flags) {
     if (!out || !in_off || n_units == 0) return ZGPU_E_ARG;
     if (ctype < 0 || ctype > 2 || lazy < 0) return ZGPU_E_ARG;
-    for (uint32_t i = 0; i < n_units; ++i) {
+    for (uint32_t i = 0; i < n_units; ++i) {  // argument errors come before any device work
         if (in_off[i + 1] < in_off[i]) return ZGPU_E_ARG;
         if (in_off[i + 1] - in_off[i] > ZGPU_MAX_UNIT_BYTES) return ZGPU_E_TOOBIG;
     }
@@ -425,171 +891,25 @@ int zgpu_plan_create(zgpu_plan **out, const uint64_t *in_off, uint32_t n_units, 
     if (rc) return rc;
     auto *p = new (std::nothrow) zgpu_plan();
     if (!p) return ZGPU_E_NOMEM;
+    ++g_live;
     p->ds = ds;
-    p->n_units = n_units;
-    p->ctype = ctype;
-    p->lazy = lazy;
-    p->flags = flags;
-    p->in_total = in_off[n_units];
-    // ---- pieces: what the kernels work on.  A unit longer than twice the split size is cut
-    // into pieces of that size, each compressed by its own workgroup as a chunk of the unit's
-    // stream: byte-aligned end (empty stored block), window primed with the 32 KiB before it.
-    // A unit's pieces are consecutive, so its output is their concatenation.
-    const bool chunked = (flags & ZGPU_F_SYNC_ALIGN) && !(flags & ZGPU_F_FINAL_EACH);
-    const bool prime_units = chunked && (flags & ZGPU_F_PRIME_WINDOW);
-    // Piece size: a batch with fewer units than kPiecesPerCu per CU (the unit queue then balances
-    // poorly at its tail, and the emit kernel's workgroups run short) cuts units longer than two
-    // pieces into pieces of total / (kPiecesPerCu x CUs) bytes, between 128 KiB and the set limit.
-    constexpr uint32_t kPiecesPerCu = 16;
-    uint64_t piece = 0;
-    if (ctype != ZGPU_NONE && g_split_bytes && n_units < kPiecesPerCu * (uint32_t)ds->cus) {
-        piece = align_up((in_off[n_units] - in_off[0]) / ((uint64_t)kPiecesPerCu * (uint64_t)ds->cus) + 1, 65536);
-        if (piece < (128u << 10)) piece = 128u << 10;
-        if (piece > g_split_bytes) piece = g_split_bytes;
+    uint64_t history = 0;
+    if (flags & ZGPU_F_PRIME_FIRST) history = in_off[0] < 32768 ? in_off[0] : 32768;
+    rc = plan_setup(p, in_off, n_units, ctype, lazy, flags, history, nullptr, false);
+    if (rc) {
+        zgpu_plan_destroy(p);
+        return rc;
     }
-    std::vector<uint64_t> pc_off;        // piece offsets into the input, n_pieces + 1
-    std::vector<uint32_t> first_piece;   // per unit, n_units + 1
-    std::vector<uint32_t> pc_prime;      // bytes of the same stream before the piece that prime its window
-    std::vector<uint8_t> pc_final;       // piece ends its stream (BFINAL) / ends with an empty stored block
-    for (uint32_t i = 0; i < n_units; ++i) {
-        const uint64_t o = in_off[i], n = in_off[i + 1] - o;
-        const uint64_t split = (piece && n > 2 * piece) ? piece : 0;
-        const uint64_t np = split ? (n + split - 1) / split : 1;
-        const bool unit_final = !chunked || ((flags & ZGPU_F_FINAL_LAST) && i == n_units - 1);
-        first_piece.push_back((uint32_t)pc_off.size());
-        for (uint64_t k = 0; k < np; ++k) {
-            pc_off.push_back(o + k * split);
-            uint64_t before = k ? k * split : (prime_units ? o - in_off[0] : 0);
-            if (before > 32768) before = 32768;
-            pc_prime.push_back((uint32_t)before & ~63u);
-            pc_final.push_back(unit_final && k == np - 1);
-        }
-        if (pc_off.size() > 0x7fffffffull) {
-            delete p;
-            return ZGPU_E_TOOBIG;
-        }
-    }
-    const uint32_t n_pieces = (uint32_t)pc_off.size();
-    first_piece.push_back(n_pieces);
-    pc_off.push_back(in_off[n_units]);
-    p->n_pieces = n_pieces;
-    p->split = n_pieces != n_units;
-    std::vector<uint64_t> slot(n_pieces + 1);
-    uint64_t acc = 0;
-    for (uint32_t i = 0; i < n_pieces; ++i) {
-        slot[i] = acc;
-        acc += align_up(zgpu_deflate_bound(pc_off[i + 1] - pc_off[i]) + 32, 16);
-    }
-    slot[n_pieces] = acc;
-    p->tmp_bytes = acc;
-    p->out_bound = acc;
-    // Token scratch: 2 bytes per input byte in the worst case.  Pieces are cut into rounds
-    // whose tokens fit a buffer of at most a third of the free device memory (ZGPU_TOK_BYTES
-    // overrides; never less than one maximum-size piece needs).
-    std::vector<uint64_t> tok_off(n_pieces);
-    std::vector<uint32_t> blk_first(n_pieces);
-    uint64_t tok_buf_tokens = 0, n_blocks = 0;
-    if (ctype != ZGPU_NONE) {
-        size_t free_b = 0, total_b = 0;
-        uint64_t cap_bytes = 8ull << 30;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap_bytes = free_b / 3;
-        if (const char *e = getenv("ZGPU_TOK_BYTES")) cap_bytes = strtoull(e, nullptr, 10);
-        const uint64_t cap_tokens = cap_bytes / 2;
-        uint64_t used = 0;
-        uint32_t first = 0;
-        for (uint32_t i = 0; i < n_pieces; ++i) {
-            const uint64_t n = pc_off[i + 1] - pc_off[i], need = unit_tok_cap(n);
-            if (used && used + need > cap_tokens) {
-                p->rounds.push_back({first, i});
-                first = i;
-                used = 0;
-            }
-            tok_off[i] = used;
-            used += need;
-            if (used > tok_buf_tokens) tok_buf_tokens = used;
-            if (n_blocks + unit_blocks(n) > 0xffffffffull) {
-                delete p;
-                return ZGPU_E_TOOBIG;
-            }
-            blk_first[i] = (uint32_t)n_blocks;
-            n_blocks += unit_blocks(n);
-        }
-        p->rounds.push_back({first, n_pieces});
-    }
-#define PCHK(expr)                 \
-    do {                           \
-        hipError_t e_ = (expr);    \
-        if (e_ != hipSuccess) {    \
-            g_last_hip = (int)e_;  \
-            zgpu_plan_destroy(p);  \
-            return e_ == hipErrorOutOfMemory ? ZGPU_E_NOMEM : ZGPU_E_NODEVICE; \
-        }                          \
-    } while (0)
-    const size_t offb = (size_t)(n_pieces + 1) * 8, uoffb = (size_t)(n_units + 1) * 8;
-    PCHK(hipMalloc(&p->d_in_off, offb));
-    PCHK(hipMalloc(&p->d_slot_off, offb));
-    PCHK(hipMalloc(&p->d_out_off, offb));
-    PCHK(hipMalloc(&p->d_out_size, (size_t)n_pieces * 4));
-    PCHK(hipMalloc(&p->d_status, (size_t)n_pieces * 4));
-    PCHK(hipMalloc(&p->d_prime, (size_t)n_pieces * 4));
-    PCHK(hipMalloc(&p->d_final, (size_t)n_pieces));
-    PCHK(hipMalloc(&p->d_crc, (size_t)n_units * 4));
-    PCHK(hipMalloc(&p->d_adler, (size_t)n_units * 4));
-    PCHK(hipMalloc(&p->d_counter, (p->rounds.size() * 2 + 2) * 4));
-    PCHK(hipMalloc(&p->d_out_tmp, p->tmp_bytes + 64));
-    if (ctype != ZGPU_NONE) {
-        PCHK(hipMalloc(&p->d_tok, (size_t)tok_buf_tokens * 2 + 64));
-        PCHK(hipMalloc(&p->d_tok_off, (size_t)n_pieces * 8));
-        PCHK(hipMalloc(&p->d_blk_first, (size_t)n_pieces * 4));
-        PCHK(hipMalloc(&p->d_hist, (size_t)n_blocks * 320 * 4));
-        PCHK(hipMalloc(&p->d_ntok, (size_t)n_blocks * 4));
-        PCHK(hipMemcpy(p->d_tok_off, tok_off.data(), (size_t)n_pieces * 8, hipMemcpyHostToDevice));
-        PCHK(hipMemcpy(p->d_blk_first, blk_first.data(), (size_t)n_pieces * 4, hipMemcpyHostToDevice));
-    }
-    PCHK(hipMemcpy(p->d_in_off, pc_off.data(), offb, hipMemcpyHostToDevice));
-    PCHK(hipMemcpy(p->d_slot_off, slot.data(), offb, hipMemcpyHostToDevice));
-    PCHK(hipMemcpy(p->d_prime, pc_prime.data(), (size_t)n_pieces * 4, hipMemcpyHostToDevice));
-    PCHK(hipMemcpy(p->d_final, pc_final.data(), (size_t)n_pieces, hipMemcpyHostToDevice));
-    if (p->split) {
-        // the caller's view: unit offsets into the input, first piece of every unit, output offsets
-        PCHK(hipMalloc(&p->d_unit_in_off, uoffb));
-        PCHK(hipMalloc(&p->d_first_piece, (size_t)(n_units + 1) * 4));
-        PCHK(hipMalloc(&p->d_unit_out_off, uoffb));
-        PCHK(hipMemcpy(p->d_unit_in_off, in_off, uoffb, hipMemcpyHostToDevice));
-        PCHK(hipMemcpy(p->d_first_piece, first_piece.data(), (size_t)(n_units + 1) * 4, hipMemcpyHostToDevice));
-        p->first_piece = first_piece;
-    }
-    PCHK(hipMemset(p->d_crc, 0, (size_t)n_units * 4));
-    PCHK(hipMemset(p->d_adler, 0, (size_t)n_units * 4));
-    for (int i = 0; i < 5; ++i) PCHK(hipEventCreate(&p->ev[i]));
-#undef PCHK
     *out = p;
     return ZGPU_OK;
 }
 
 void zgpu_plan_destroy(zgpu_plan *p) {
     if (!p) return;
-    (void)hipFree(p->d_in_off);
-    (void)hipFree(p->d_slot_off);
-    (void)hipFree(p->d_out_off);
-    (void)hipFree(p->d_out_size);
-    (void)hipFree(p->d_status);
-    (void)hipFree(p->d_crc);
-    (void)hipFree(p->d_adler);
-    (void)hipFree(p->d_counter);
-    (void)hipFree(p->d_out_tmp);
-    (void)hipFree(p->d_tok);
-    (void)hipFree(p->d_tok_off);
-    (void)hipFree(p->d_blk_first);
-    (void)hipFree(p->d_hist);
-    (void)hipFree(p->d_ntok);
-    (void)hipFree(p->d_prime);
-    (void)hipFree(p->d_final);
-    (void)hipFree(p->d_unit_in_off);
-    (void)hipFree(p->d_unit_out_off);
-    (void)hipFree(p->d_first_piece);
+    p->release_buffers();
     for (int i = 0; i < 5; ++i)
         if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
+    if (!p->pooled) --g_live;
     delete p;
 }
 
@@ -599,12 +919,13 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
     if (!p || !d_out || (!d_in && p->in_total)) return ZGPU_E_ARG;
     hipStream_t st = (hipStream_t)stream_;
     HIPCHK(hipEventRecord(p->ev[0], st));
-    HIPCHK(hipMemsetAsync(p->d_counter, 0, (p->rounds.size() * 2 + 2) * 4, st));
+    HIPCHK(hipMemsetAsync(p->d_counter(), 0, (p->rounds.size() * 2 + 2) * 4, st));
     HIPCHK(hipEventRecord(p->ev[1], st));
+    uint8_t *d_out_tmp = p->b_out_tmp.as<uint8_t>();
     if (p->ctype == ZGPU_NONE) {
         int grid = p->n_units < (uint32_t)p->ds->cus * 8 ? (int)p->n_units : p->ds->cus * 8;
         hipLaunchKernelGGL(zgpu_stored_kernel, dim3(grid), dim3(256), 0, st, (const uint8_t *)d_in,
-                           p->d_in_off, p->d_slot_off, p->d_out_tmp, p->d_out_size, p->d_status,
+                           p->d_in_off, p->d_slot_off, d_out_tmp, p->d_out_size(), p->d_status(),
                            p->n_units, p->flags);
         HIPCHK(hipEventRecord(p->ev[4], st));
     } else {
@@ -613,23 +934,25 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             Params P;
             P.in = (const uint8_t *)d_in;
             P.in_off = p->d_in_off;
-            P.tok = p->d_tok;
+            P.tok = p->b_tok.as<uint16_t>();
             P.tok_off = p->d_tok_off;
             P.blk_first = p->d_blk_first;
-            P.hist = p->d_hist;
-            P.ntok = p->d_ntok;
-            P.counter = p->d_counter + 2 * r;
+            P.hist = p->b_hist.as<uint32_t>();
+            P.ntok = p->b_ntok.as<uint32_t>();
+            P.counter = p->d_counter() + 2 * r;
             P.unit_first = first;
             P.unit_end = end;
-            P.lazy = p->lazy > g_min_lazy ? p->lazy : g_min_lazy;
-            P.max_chain = g_max_chain;
-            P.nice = g_nice;
-            P.deep = g_deep;
-            P.fan = g_fan;
+            // the caller's lazy is the threshold below which a match is deferred when the next
+            // position matches longer; min_lazy (default 258: always) is its floor
+            P.lazy = p->lazy > p->knobs.min_lazy ? p->lazy : p->knobs.min_lazy;
+            P.max_chain = p->knobs.max_chain;
+            P.nice = p->knobs.nice;
+            P.deep = p->knobs.deep;
+            P.fan = p->knobs.fan;
             P.unit_prime = p->d_prime;
             P.prof = g_prof;
             const int sgrid = (int)(cnt < (uint32_t)p->ds->cus ? cnt : (uint32_t)p->ds->cus);
-            if (g_nice > 32)
+            if (p->knobs.nice > 32)
                 hipLaunchKernelGGL(zgpu_deflate_thorough_kernel, dim3(sgrid), dim3(1024), 0, st, P);
             else
                 hipLaunchKernelGGL(zgpu_deflate_kernel, dim3(sgrid), dim3(1024), 0, st, P);
@@ -637,15 +960,15 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             EParams E;
             E.in_off = p->d_in_off;
             E.slot_off = p->d_slot_off;
-            E.out_tmp = p->d_out_tmp;
-            E.out_size = p->d_out_size;
-            E.status = p->d_status;
-            E.tok = p->d_tok;
+            E.out_tmp = d_out_tmp;
+            E.out_size = p->d_out_size();
+            E.status = p->d_status();
+            E.tok = p->b_tok.as<uint16_t>();
             E.tok_off = p->d_tok_off;
             E.blk_first = p->d_blk_first;
-            E.hist = p->d_hist;
-            E.ntok = p->d_ntok;
-            E.counter = p->d_counter + 2 * r + 1;
+            E.hist = p->b_hist.as<uint32_t>();
+            E.ntok = p->b_ntok.as<uint32_t>();
+            E.counter = p->d_counter() + 2 * r + 1;
             E.unit_first = first;
             E.unit_end = end;
             E.unit_final = p->d_final;
@@ -656,22 +979,22 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(p->ev[2], st));
-    hipLaunchKernelGGL(zgpu_scan_kernel, dim3(1), dim3(1024), 0, st, p->d_out_size, p->d_out_off,
+    hipLaunchKernelGGL(zgpu_scan_kernel, dim3(1), dim3(1024), 0, st, p->d_out_size(), p->d_out_off(),
                        p->n_pieces);
     {
         int grid = p->n_pieces < (uint32_t)p->ds->cus * 8 ? (int)p->n_pieces : p->ds->cus * 8;
-        hipLaunchKernelGGL(zgpu_compact_kernel, dim3(grid), dim3(256), 0, st, p->d_out_tmp,
-                           p->d_slot_off, p->d_out_off, (uint8_t *)d_out, out_cap, p->d_status,
+        hipLaunchKernelGGL(zgpu_compact_kernel, dim3(grid), dim3(256), 0, st, d_out_tmp,
+                           p->d_slot_off, p->d_out_off(), (uint8_t *)d_out, out_cap, p->d_status(),
                            p->n_pieces);
     }
     if (p->split)
-        hipLaunchKernelGGL(zgpu_unit_offsets_kernel, dim3(p->n_units / 256 + 1), dim3(256), 0, st, p->d_out_off,
-                           p->d_first_piece, p->d_unit_out_off, p->n_units);
+        hipLaunchKernelGGL(zgpu_unit_offsets_kernel, dim3(p->n_units / 256 + 1), dim3(256), 0, st, p->d_out_off(),
+                           p->d_first_piece, p->d_unit_out_off(), p->n_units);
     if (p->flags & (ZGPU_F_WANT_CRC | ZGPU_F_WANT_ADLER)) {
         int grid = p->n_units < (uint32_t)p->ds->cus * 8 ? (int)p->n_units : p->ds->cus * 8;
         hipLaunchKernelGGL(zgpu_checksum_kernel, dim3(grid), dim3(ZGPU_CK_THREADS), 0, st,
                            (const uint8_t *)d_in, p->split ? p->d_unit_in_off : p->d_in_off, p->n_units,
-                           p->ds->d_tables, p->d_crc, p->d_adler);
+                           p->ds->d_tables, p->d_crc(), p->d_adler());
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(p->ev[3], st));
@@ -680,26 +1003,32 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
 }
 
 const uint64_t *zgpu_plan_out_off_device(const zgpu_plan *p) {
-    return p ? (p->split ? p->d_unit_out_off : p->d_out_off) : nullptr;
+    return p ? (p->split ? p->d_unit_out_off() : p->d_out_off()) : nullptr;
 }
-const uint32_t *zgpu_plan_crc_device(const zgpu_plan *p) { return p ? p->d_crc : nullptr; }
-const uint32_t *zgpu_plan_adler_device(const zgpu_plan *p) { return p ? p->d_adler : nullptr; }
+const uint32_t *zgpu_plan_crc_device(const zgpu_plan *p) { return p ? p->d_crc() : nullptr; }
+const uint32_t *zgpu_plan_adler_device(const zgpu_plan *p) { return p ? p->d_adler() : nullptr; }
 
 int zgpu_plan_fetch(zgpu_plan *p, uint64_t *out_off, uint32_t *crc32, uint32_t *adler32, void *stream_) {
     if (!p || !p->ran) return ZGPU_E_ARG;
     hipStream_t st = (hipStream_t)stream_;
-    HIPCHK(hipStreamSynchronize(st));
-    std::vector<uint32_t> status(p->n_pieces);
-    HIPCHK(hipMemcpy(status.data(), p->d_status, (size_t)p->n_pieces * 4, hipMemcpyDeviceToHost));
+    try {
+        p->h_status.resize(p->n_pieces);
+    } catch (const std::bad_alloc &) {
+        return ZGPU_E_NOMEM;
+    }
+    // the copies ride on the run's stream (not on the null stream, which would wait for every other
+    // stream of the process); one wait at the end
+    HIPCHK(hipMemcpyAsync(p->h_status.data(), p->d_status(), (size_t)p->n_pieces * 4, hipMemcpyDeviceToHost, st));
     if (out_off)
-        HIPCHK(hipMemcpy(out_off, p->split ? p->d_unit_out_off : p->d_out_off, (size_t)(p->n_units + 1) * 8,
-                         hipMemcpyDeviceToHost));
-    if (crc32) HIPCHK(hipMemcpy(crc32, p->d_crc, (size_t)p->n_units * 4, hipMemcpyDeviceToHost));
-    if (adler32) HIPCHK(hipMemcpy(adler32, p->d_adler, (size_t)p->n_units * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(out_off, p->split ? p->d_unit_out_off() : p->d_out_off(), (size_t)(p->n_units + 1) * 8,
+                              hipMemcpyDeviceToHost, st));
+    if (crc32) HIPCHK(hipMemcpyAsync(crc32, p->d_crc(), (size_t)p->n_units * 4, hipMemcpyDeviceToHost, st));
+    if (adler32) HIPCHK(hipMemcpyAsync(adler32, p->d_adler(), (size_t)p->n_units * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     int rc = ZGPU_OK;
     for (uint32_t i = 0; i < p->n_pieces; ++i) {
-        if (status[i] == 2) rc = ZGPU_E_OUTCAP;
-        else if (status[i] && rc == ZGPU_OK) rc = ZGPU_E_UNIT;
+        if (p->h_status[i] == 2) rc = ZGPU_E_OUTCAP;
+        else if (p->h_status[i] && rc == ZGPU_OK) rc = ZGPU_E_UNIT;
     }
     return rc;
 }
@@ -723,55 +1052,214 @@ int zgpu_plan_phase_ms(zgpu_plan *p, float *search_ms, float *emit_ms) {
     return ZGPU_OK;
 }
 
+// ---- host-buffer batches ------------------------------------------------------------------
+int zgpu_host_devices(int *device_ids, int cap) {
+    std::vector<int> devs;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        devs = g_allowed;
+    }
+    if (devs.empty()) {
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) return ZGPU_E_NODEVICE;
+        devs.push_back(cur);
+    }
+    for (int i = 0; i < (int)devs.size() && i < cap; ++i)
+        if (device_ids) device_ids[i] = devs[i];
+    return (int)devs.size();
+}
+
+int zgpu_partition_units(const uint64_t *in_off, uint32_t n_units, int n_parts, uint32_t *cut) {
+    if (!in_off || !cut || n_parts < 1) return ZGPU_E_ARG;
+    for (uint32_t i = 0; i < n_units; ++i)
+        if (in_off[i + 1] < in_off[i]) return ZGPU_E_ARG;
+    std::vector<uint32_t> c;
+    split_units_by_bytes(in_off, n_units, n_parts, c);
+    memcpy(cut, c.data(), ((size_t)n_parts + 1) * sizeof(uint32_t));
+    return ZGPU_OK;
+}
+
+static int host_batch_compute(const uint8_t *in, const uint64_t *in_off, uint32_t n_units, int ctype, int lazy,
+                              uint32_t flags, uint8_t *out, uint64_t out_cap, zgpu_job **job_out) {
+    *job_out = nullptr;
+    if (!in_off || n_units == 0) return ZGPU_E_ARG;
+    if (ctype < 0 || ctype > 2 || lazy < 0) return ZGPU_E_ARG;
+    for (uint32_t i = 0; i < n_units; ++i) {
+        if (in_off[i + 1] < in_off[i]) return ZGPU_E_ARG;
+        if (in_off[i + 1] - in_off[i] > ZGPU_MAX_UNIT_BYTES) return ZGPU_E_TOOBIG;
+    }
+    if (in_off[n_units] > in_off[0] && !in) return ZGPU_E_ARG;
+    int prev_dev = 0;
+    HIPCHK(hipGetDevice(&prev_dev));
+    // devices: the ones zgpu_init named (all of them share a large batch), else the current one
+    std::vector<int> devs;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        devs = g_allowed;
+    }
+    if (devs.empty()) devs.push_back(prev_dev);
+    const uint64_t total = in_off[n_units] - in_off[0];
+    // a device is worth its own range only from a few sub-batches of input on
+    size_t use = (size_t)(total / (2 * kSubBytes)) + 1;
+    if (use > devs.size()) use = devs.size();
+    if (use > n_units) use = n_units;
+    if (use == 1) {
+        // small batch: the caller's current device if it is among the named ones
+        for (int d : devs)
+            if (d == prev_dev) devs[0] = prev_dev;
+    }
+    devs.resize(use);
+    std::unique_ptr<zgpu_job> j(new (std::nothrow) zgpu_job());
+    if (!j) return ZGPU_E_NOMEM;
+    ++g_live;
+    int rc = ZGPU_OK;
+    auto restore = [&]() { (void)hipSetDevice(prev_dev); };
+    try {
+        j->n_units = n_units;
+        j->out_off.assign((size_t)n_units + 1, 0);
+        if (flags & ZGPU_F_WANT_CRC) j->crc.assign(n_units, 0);
+        if (flags & ZGPU_F_WANT_ADLER) j->adler.assign(n_units, 0);
+        std::vector<uint32_t> cut;
+        split_units_by_bytes(in_off, n_units, (int)use, cut);
+        j->devs.resize(use);
+        for (size_t d = 0; d < use && rc == ZGPU_OK; ++d) {
+            zgpu_job::Dev &dv = j->devs[d];
+            dv.device = devs[d];
+            if (hipSetDevice(dv.device) != hipSuccess) {
+                rc = ZGPU_E_NODEVICE;
+                break;
+            }
+            if ((rc = get_state(&dv.ds)) != ZGPU_OK) break;
+            if ((rc = get_host_ctx(dv.ds, &dv.ctx)) != ZGPU_OK) break;
+            // sub-batches of this device's range: about kSubBytes each, at least one unit
+            uint32_t u = cut[d];
+            while (u < cut[d + 1]) {
+                SubBatch sb;
+                sb.first = u;
+                sb.dev_index = (int)d;
+                uint64_t bytes = 0;
+                do {
+                    bytes += in_off[u + 1] - in_off[u];
+                    ++u;
+                } while (u < cut[d + 1] && bytes + (in_off[u + 1] - in_off[u]) <= kSubBytes);
+                sb.end = u;
+                sb.res_off = dv.res_need;
+                uint64_t bound = 0;
+                for (uint32_t i = sb.first; i < sb.end; ++i)
+                    bound += align_up(zgpu_deflate_bound(in_off[i + 1] - in_off[i]) + 32, 16);
+                // pieces of cut units add per-piece slack: the plan's own bound is what counts, and it
+                // never exceeds the per-unit bound by more than the piece framing already inside it
+                sb.res_cap = align_up(bound + bytes / 64 + (uint64_t)(sb.end - sb.first) * 64 + 4096, 256);
+                dv.res_need += sb.res_cap;
+                j->subs.push_back(sb);
+            }
+            // result buffer: the device's spare one if it is large enough, else a new one
+            {
+                std::lock_guard<std::mutex> lk(g_mu);
+                std::swap(dv.d_res, dv.ctx->d_res);
+            }
+            rc = dv.d_res.ensure(dv.res_need + 64);
+        }
+    } catch (const std::bad_alloc &) {
+        rc = ZGPU_E_NOMEM;
+    }
+    if (rc) {
+        restore();
+        zgpu_job_release(j.release());
+        return rc;
+    }
+    BatchShared S;
+    S.in = in;
+    S.in_off = in_off;
+    S.n_units = n_units;
+    S.ctype = ctype;
+    S.lazy = lazy;
+    S.flags = flags;
+    S.job = j.get();
+    if (use == 1 && out) {  // one device and the caller's buffer at hand: copy out as sub-batches finish
+        S.out = out;
+        S.out_cap = out_cap;
+    }
+    if (use == 1) {
+        run_device(S, 0);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t d = 1; d < use; ++d) th.emplace_back(run_device, std::ref(S), (int)d);
+        run_device(S, 0);
+        for (auto &t : th) t.join();
+    }
+    restore();
+    if (S.rc) {
+        zgpu_job_release(j.release());
+        return S.rc;
+    }
+    // per-unit offsets: the sub-batches' own offsets shifted to their place in the whole output
+    uint64_t at = 0;
+    for (SubBatch &sb : j->subs) {
+        // out_off[first..end) are relative to the sub-batch; out_off[end] is overwritten by the next
+        // sub-batch's first entry (0), so its size was saved
+        for (uint32_t i = sb.first; i < sb.end; ++i) j->out_off[i] += at;
+        at += sb.out_bytes;
+    }
+    j->out_off[n_units] = at;
+    *job_out = j.release();
+    return ZGPU_OK;
+}
+
+// copies what is still on the devices to out (sub-batches side by side, two threads per device)
+static int host_batch_copy_out(zgpu_job *j, uint8_t *out) {
+    int prev_dev = 0;
+    HIPCHK(hipGetDevice(&prev_dev));
+    std::vector<uint64_t> at(j->subs.size());
+    uint64_t a = 0;
+    for (size_t i = 0; i < j->subs.size(); ++i) {
+        at[i] = a;
+        a += j->subs[i].out_bytes;
+    }
+    std::mutex mu;
+    int rc = ZGPU_OK;
+    auto worker = [&](int dev_index, int part, int parts) {
+        zgpu_job::Dev &dv = j->devs[dev_index];
+        hipStream_t st = dv.ctx->slot[part].st;
+        bool ok = hipSetDevice(dv.device) == hipSuccess;
+        int k = 0;
+        for (size_t i = 0; i < j->subs.size() && ok; ++i) {
+            const SubBatch &sb = j->subs[i];
+            if (sb.dev_index != dev_index || !sb.out_bytes) continue;
+            if (k++ % parts != part) continue;
+            ok = hipMemcpyAsync(out + at[i], dv.d_res.as<uint8_t>() + sb.res_off, sb.out_bytes, hipMemcpyDeviceToHost,
+                                st) == hipSuccess;
+        }
+        ok = ok && hipStreamSynchronize(st) == hipSuccess;
+        if (!ok) {
+            std::lock_guard<std::mutex> lk(mu);
+            rc = ZGPU_E_NODEVICE;
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t d = 0; d < j->devs.size(); ++d) {
+        std::lock_guard<std::mutex> ctx_lock(j->devs[d].ctx->mu);  // the slots' streams are the context's
+        size_t mine = 0;
+        for (const SubBatch &sb : j->subs) mine += sb.dev_index == (int)d && sb.out_bytes;
+        if (mine <= 1 && j->devs.size() == 1) {
+            worker((int)d, 0, 1);
+        } else {
+            std::vector<std::thread> t2;
+            t2.emplace_back(worker, (int)d, 1, 2);
+            worker((int)d, 0, 2);
+            t2[0].join();
+        }
+    }
+    (void)hipSetDevice(prev_dev);
+    return rc;
+}
+
 int zgpu_deflate_batch_begin(const uint8_t *in, const uint64_t *in_off, uint32_t n_units, int ctype, int lazy,
                              uint32_t flags, zgpu_job **job_out, uint64_t *out_total) {
     if (!in_off || !job_out || !out_total) return ZGPU_E_ARG;
-    *job_out = nullptr;
-    HostDeviceScope scope;
-    if (scope.rc) return scope.rc;
-    auto *j = new (std::nothrow) zgpu_job();
-    if (!j) return ZGPU_E_NOMEM;
-    auto fail = [&](int code) {
-        zgpu_job_release(j);
-        return code;
-    };
-    if (hipGetDevice(&j->device) != hipSuccess) return fail(ZGPU_E_NODEVICE);
-    int rc = zgpu_plan_create(&j->plan, in_off, n_units, ctype, lazy, flags);
-    if (rc) return fail(rc);
-    zgpu_plan *p = j->plan;
-    const uint64_t base = in_off[0], total = in_off[n_units] - base;
-    if (total && !in) return fail(ZGPU_E_ARG);
-    hipError_t e;
-    // The plan indexes its input with the caller's absolute offsets: only the bytes of the
-    // units are allocated and copied, and the base pointer handed to the plan is moved back by
-    // the first offset (kept congruent modulo 256 so the kernels see the caller's alignment).
-    const uint64_t lead = base & 255u;
-    if ((e = hipMalloc(&j->d_in, lead + total + 64)) != hipSuccess) { g_last_hip = e; return fail(ZGPU_E_NOMEM); }
-    if ((e = hipMalloc(&j->d_out, p->out_bound + 64)) != hipSuccess) { g_last_hip = e; return fail(ZGPU_E_NOMEM); }
-    if (total && (e = hipMemcpy(j->d_in + lead, in + base, total, hipMemcpyHostToDevice)) != hipSuccess) {
-        g_last_hip = e;
-        return fail(ZGPU_E_NODEVICE);
-    }
-    const uint8_t *d_in0 = (const uint8_t *)((uintptr_t)j->d_in + lead - base);
-    rc = zgpu_plan_run(p, d_in0, j->d_out, p->out_bound, nullptr);
-    if (rc) return fail(rc);
-    try {
-        j->out_off.resize((size_t)n_units + 1);
-        if (flags & ZGPU_F_WANT_CRC) j->crc.resize(n_units);
-        if (flags & ZGPU_F_WANT_ADLER) j->adler.resize(n_units);
-    } catch (const std::bad_alloc &) {
-        return fail(ZGPU_E_NOMEM);
-    }
-    rc = zgpu_plan_fetch(p, j->out_off.data(), j->crc.empty() ? nullptr : j->crc.data(),
-                         j->adler.empty() ? nullptr : j->adler.data(), nullptr);
-    if (rc) return fail(rc);
-    // the workspace is no longer needed; the compressed bytes wait on the device
-    zgpu_plan_destroy(j->plan);
-    j->plan = nullptr;
-    (void)hipFree(j->d_in);
-    j->d_in = nullptr;
-    *out_total = j->out_off[n_units];
-    *job_out = j;
+    int rc = host_batch_compute(in, in_off, n_units, ctype, lazy, flags, nullptr, 0, job_out);
+    if (rc) return rc;
+    *out_total = (*job_out)->out_off[n_units];
     return ZGPU_OK;
 }
 
@@ -779,21 +1267,15 @@ int zgpu_deflate_batch_finish(zgpu_job *j, uint8_t *out, uint64_t out_cap, uint6
                               uint32_t *adler32) {
     if (!j) return ZGPU_E_ARG;
     int rc = ZGPU_OK;
-    const size_t n = j->out_off.size() - 1;
+    const size_t n = j->n_units;
     const uint64_t total = j->out_off[n];
     if (!out_off || (total && !out) || (crc32 && j->crc.empty()) || (adler32 && j->adler.empty())) {
         rc = ZGPU_E_ARG;
     } else if (total > out_cap) {
         rc = ZGPU_E_OUTCAP;
     } else {
-        int cur = 0;
-        const bool moved = hipGetDevice(&cur) == hipSuccess && cur != j->device && hipSetDevice(j->device) == hipSuccess;
-        hipError_t e = total ? hipMemcpy(out, j->d_out, total, hipMemcpyDeviceToHost) : hipSuccess;
-        if (moved) (void)hipSetDevice(cur);
-        if (e != hipSuccess) {
-            g_last_hip = e;
-            rc = ZGPU_E_NODEVICE;
-        } else {
+        rc = total ? host_batch_copy_out(j, out) : ZGPU_OK;
+        if (rc == ZGPU_OK) {
             memcpy(out_off, j->out_off.data(), (n + 1) * sizeof(uint64_t));
             if (crc32) memcpy(crc32, j->crc.data(), n * sizeof(uint32_t));
             if (adler32) memcpy(adler32, j->adler.data(), n * sizeof(uint32_t));
@@ -806,12 +1288,23 @@ int zgpu_deflate_batch_finish(zgpu_job *j, uint8_t *out, uint64_t out_cap, uint6
 void zgpu_job_release(zgpu_job *j) {
     if (!j) return;
     int cur = 0;
-    const bool moved = j->device >= 0 && hipGetDevice(&cur) == hipSuccess && cur != j->device &&
-                       hipSetDevice(j->device) == hipSuccess;
-    zgpu_plan_destroy(j->plan);
-    (void)hipFree(j->d_in);
-    (void)hipFree(j->d_out);
-    if (moved) (void)hipSetDevice(cur);
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (zgpu_job::Dev &dv : j->devs) {
+        if (!dv.d_res.p) continue;
+        // the result buffer goes back to its device as the spare one (or is released if the
+        // device already has a spare at least as large)
+        bool kept = false;
+        if (dv.ctx) {
+            std::lock_guard<std::mutex> lk(g_mu);
+            if (dv.ctx->d_res.cap < dv.d_res.cap) {
+                std::swap(dv.ctx->d_res, dv.d_res);
+                kept = dv.d_res.p == nullptr;
+            }
+        }
+        if (!kept && dv.d_res.p && hipSetDevice(dv.device) == hipSuccess) dv.d_res.release();
+    }
+    if (have_cur) (void)hipSetDevice(cur);
+    --g_live;
     delete j;
 }
 
@@ -822,10 +1315,21 @@ int zgpu_deflate_batch(const uint8_t *in, const uint64_t *in_off, uint32_t n_uni
     if (crc32) flags |= ZGPU_F_WANT_CRC;
     if (adler32) flags |= ZGPU_F_WANT_ADLER;
     zgpu_job *job = nullptr;
-    uint64_t total = 0;
-    int rc = zgpu_deflate_batch_begin(in, in_off, n_units, ctype, lazy, flags, &job, &total);
+    int rc = host_batch_compute(in, in_off, n_units, ctype, lazy, flags, out, out_cap, &job);
     if (rc) return rc;
-    return zgpu_deflate_batch_finish(job, out, out_cap, out_off, crc32, adler32);
+    const uint64_t total = job->out_off[n_units];
+    if (job->devs.size() > 1) {
+        // several devices: nothing was copied yet (a device's place in out depends on the ones before it)
+        if (total > out_cap) rc = ZGPU_E_OUTCAP;
+        else if (total) rc = host_batch_copy_out(job, out);
+    }
+    if (rc == ZGPU_OK) {
+        memcpy(out_off, job->out_off.data(), ((size_t)n_units + 1) * sizeof(uint64_t));
+        if (crc32) memcpy(crc32, job->crc.data(), (size_t)n_units * sizeof(uint32_t));
+        if (adler32) memcpy(adler32, job->adler.data(), (size_t)n_units * sizeof(uint32_t));
+    }
+    zgpu_job_release(job);
+    return rc;
 }
 
 // ---- checksums -------------------------------------------------------------
@@ -845,58 +1349,52 @@ uint32_t zgpu_adler32_combine(uint32_t a, uint32_t b, uint64_t len_b) {
 
 int zgpu_checksum_device(const void *d_in, uint64_t len, uint32_t *crc32, uint32_t *adler32,
                          void *stream_) {
+    if (!d_in && len) return ZGPU_E_ARG;
     DeviceState *ds = nullptr;
     int rc = get_state(&ds);
     if (rc) return rc;
     std::lock_guard<std::mutex> ck_lock(ds->ck_mu);
+    if (!ds->ck) {
+        ds->ck = new (std::nothrow) CkScratch();
+        if (!ds->ck) return ZGPU_E_NOMEM;
+    }
+    CkScratch &K = *ds->ck;
     hipStream_t st = (hipStream_t)stream_;
     // large buffers go through the wide kernel (one workgroup per CU, 4 MiB segments)
     const bool wide = len >= ZGPU_CKW_MIN_BYTES;
     const uint64_t seg = wide ? ZGPU_CKW_SEG : ZGPU_CK_SEG;
     const uint64_t nseg = len ? (len + seg - 1) / seg : 1;
-    if (nseg + 1 > ds->seg_cap) {
-        (void)hipFree(ds->d_seg_off);
-        (void)hipFree(ds->d_seg_crc);
-        (void)hipFree(ds->d_seg_adler);
-        ds->seg_cap = 0;
-        HIPCHK(hipMalloc(&ds->d_seg_off, (nseg + 1) * 8));
-        HIPCHK(hipMalloc(&ds->d_seg_crc, nseg * 4));
-        HIPCHK(hipMalloc(&ds->d_seg_adler, nseg * 4));
-        ds->seg_cap = nseg + 1;
-    }
-    std::vector<uint64_t> off(nseg + 1);
-    for (uint64_t i = 0; i < nseg; ++i) off[i] = i * seg;
-    off[nseg] = len;
-    HIPCHK(hipMemcpyAsync(ds->d_seg_off, off.data(), (nseg + 1) * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));  // off is a local
+    if ((rc = K.seg_off.ensure((nseg + 1) * 8)) || (rc = K.seg_crc.ensure(nseg * 4)) ||
+        (rc = K.seg_adler.ensure(nseg * 4)) || (rc = K.out2.ensure(8)))
+        return rc;
+    // segment offsets are written and the per-segment values combined on the device: the host
+    // only waits for two words
+    hipLaunchKernelGGL(zgpu_na_offsets_kernel, dim3((uint32_t)(nseg / 256 + 1)), dim3(256), 0, st,
+                       K.seg_off.as<uint64_t>(), (uint32_t)nseg, seg, len);
     HIPCHK(hipEventRecord(ds->ev0, st));
     if (wide) {
         const int grid = (int)(nseg < (uint64_t)ds->cus ? nseg : (uint64_t)ds->cus);
         hipLaunchKernelGGL(zgpu_checksum_wide_kernel, dim3(grid), dim3(ZGPU_CKW_THREADS), 0, st,
-                           (const uint8_t *)d_in, ds->d_seg_off, (uint32_t)nseg, ds->d_tables_wide,
-                           ds->d_seg_crc, ds->d_seg_adler);
+                           (const uint8_t *)d_in, K.seg_off.as<uint64_t>(), (uint32_t)nseg, ds->d_tables_wide,
+                           K.seg_crc.as<uint32_t>(), K.seg_adler.as<uint32_t>());
     } else {
         const int grid = (int)(nseg < (uint64_t)ds->cus * 8 ? nseg : (uint64_t)ds->cus * 8);
         hipLaunchKernelGGL(zgpu_checksum_kernel, dim3(grid), dim3(ZGPU_CK_THREADS), 0, st,
-                           (const uint8_t *)d_in, ds->d_seg_off, (uint32_t)nseg, ds->d_tables,
-                           ds->d_seg_crc, ds->d_seg_adler);
+                           (const uint8_t *)d_in, K.seg_off.as<uint64_t>(), (uint32_t)nseg, ds->d_tables,
+                           K.seg_crc.as<uint32_t>(), K.seg_adler.as<uint32_t>());
     }
-    HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ds->ev1, st));
-    std::vector<uint32_t> c(nseg), a(nseg);
-    HIPCHK(hipMemcpyAsync(c.data(), ds->d_seg_crc, nseg * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(a.data(), ds->d_seg_adler, nseg * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(zgpu_na_fold_kernel, dim3(1), dim3(256), 0, st, K.seg_off.as<uint64_t>(),
+                       K.seg_crc.as<uint32_t>(), K.seg_adler.as<uint32_t>(), (uint32_t)nseg, K.out2.as<uint32_t>());
+    HIPCHK(hipGetLastError());
+    uint32_t r[2] = {0, 1};
+    hipError_t e = hipMemcpyAsync(r, K.out2.p, 8, hipMemcpyDeviceToHost, st);
+    const hipError_t e2 = hipStreamSynchronize(st);  // also when the copy failed to enqueue: nothing may still write r
+    if (e == hipSuccess) e = e2;
+    HIPCHK(e);
     HIPCHK(hipEventElapsedTime(&ds->last_ck_ms, ds->ev0, ds->ev1));
-    uint32_t crc = c[0], ad = a[0];
-    const uint32_t xs = h_xpow_bytes(seg);
-    for (uint64_t i = 1; i < nseg; ++i) {
-        const uint64_t l = off[i + 1] - off[i];
-        crc = h_gf_mul(crc, l == seg ? xs : h_xpow_bytes(l)) ^ c[i];
-        ad = zgpu_adler32_combine(ad, a[i], l);
-    }
-    if (crc32) *crc32 = crc;
-    if (adler32) *adler32 = ad;
+    if (crc32) *crc32 = r[0];
+    if (adler32) *adler32 = r[1];
     return ZGPU_OK;
 }
 
@@ -964,17 +1462,58 @@ int zgpu_checksum(const uint8_t *in, uint64_t len, uint32_t *crc32, uint32_t *ad
     if (!in && len) return ZGPU_E_ARG;
     HostDeviceScope scope;
     if (scope.rc) return scope.rc;
-    uint8_t *d = nullptr;
-    HIPCHK(hipMalloc(&d, len + 64));
-    hipError_t e = len ? hipMemcpy(d, in, len, hipMemcpyHostToDevice) : hipSuccess;
-    if (e != hipSuccess) {
-        g_last_hip = e;
-        (void)hipFree(d);
-        return ZGPU_E_NODEVICE;
+    DeviceState *ds = nullptr;
+    int rc = get_state(&ds);
+    if (rc) return rc;
+    HostCtx *ctx = nullptr;
+    if ((rc = get_host_ctx(ds, &ctx)) != ZGPU_OK) return rc;
+    std::lock_guard<std::mutex> ctx_lock(ctx->mu);
+    // chunks of kSubBytes through two of the device's slots: the upload of one chunk runs while the
+    // other is summed; per-chunk values are folded on the device and combined here at the end
+    const uint64_t nchunks = len ? (len + kSubBytes - 1) / kSubBytes : 1;
+    if ((rc = ctx->ck_res.ensure(nchunks * 8)) != ZGPU_OK) return rc;
+    for (uint64_t c = 0; c < nchunks; ++c) {
+        Slot &sl = ctx->slot[c & 1];
+        const uint64_t off = c * kSubBytes, bytes = len - off < kSubBytes ? len - off : kSubBytes;
+        const uint64_t lead = (uintptr_t)(in + off) & 255u;
+        const uint64_t nseg = bytes ? (bytes + ZGPU_CK_SEG - 1) / ZGPU_CK_SEG : 1;
+        if ((rc = sl.d_in.ensure(lead + bytes + 64)) || (rc = sl.ck_off.ensure((nseg + 1) * 8)) ||
+            (rc = sl.ck_crc.ensure(nseg * 4)) || (rc = sl.ck_adler.ensure(nseg * 4)))
+            break;
+        uint8_t *d = sl.d_in.as<uint8_t>() + lead;
+        if (bytes) HIPCHK(hipMemcpyAsync(d, in + off, bytes, hipMemcpyHostToDevice, sl.st));
+        hipLaunchKernelGGL(zgpu_na_offsets_kernel, dim3((uint32_t)(nseg / 256 + 1)), dim3(256), 0, sl.st,
+                           sl.ck_off.as<uint64_t>(), (uint32_t)nseg, (uint64_t)ZGPU_CK_SEG, bytes);
+        const uint32_t grid = (uint32_t)(nseg < (uint64_t)ds->cus * 8 ? nseg : (uint64_t)ds->cus * 8);
+        hipLaunchKernelGGL(zgpu_checksum_kernel, dim3(grid), dim3(ZGPU_CK_THREADS), 0, sl.st, d,
+                           sl.ck_off.as<uint64_t>(), (uint32_t)nseg, ds->d_tables, sl.ck_crc.as<uint32_t>(),
+                           sl.ck_adler.as<uint32_t>());
+        hipLaunchKernelGGL(zgpu_na_fold_kernel, dim3(1), dim3(256), 0, sl.st, sl.ck_off.as<uint64_t>(),
+                           sl.ck_crc.as<uint32_t>(), sl.ck_adler.as<uint32_t>(), (uint32_t)nseg,
+                           ctx->ck_res.as<uint32_t>() + 2 * c);
     }
-    int rc = zgpu_checksum_device(d, len, crc32, adler32, nullptr);
-    (void)hipFree(d);
-    return rc;
+    const hipError_t e0 = hipStreamSynchronize(ctx->slot[0].st), e1 = hipStreamSynchronize(ctx->slot[1].st);
+    if (rc) return rc;
+    HIPCHK(e0);
+    HIPCHK(e1);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> r;
+    try {
+        r.resize(nchunks * 2);
+    } catch (const std::bad_alloc &) {
+        return ZGPU_E_NOMEM;
+    }
+    HIPCHK(hipMemcpyAsync(r.data(), ctx->ck_res.p, nchunks * 8, hipMemcpyDeviceToHost, ctx->slot[0].st));
+    HIPCHK(hipStreamSynchronize(ctx->slot[0].st));
+    uint32_t crc = r[0], ad = r[1];
+    for (uint64_t c = 1; c < nchunks; ++c) {
+        const uint64_t off = c * kSubBytes, bytes = len - off < kSubBytes ? len - off : kSubBytes;
+        crc = zgpu_crc32_combine(crc, r[2 * c], bytes);
+        ad = zgpu_adler32_combine(ad, r[2 * c + 1], bytes);
+    }
+    if (crc32) *crc32 = crc;
+    if (adler32) *adler32 = ad;
+    return ZGPU_OK;
 }
 
 int zgpu_crc32_update(const uint8_t *in, uint64_t len, uint32_t crc, uint32_t *out) {

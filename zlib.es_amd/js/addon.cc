@@ -33,12 +33,14 @@ struct Lib {
     fn_deflate_batch deflate_batch = nullptr;
     fn_batch_begin batch_begin = nullptr;
     fn_batch_finish batch_finish = nullptr;
+    void (*job_release)(void *) = nullptr;
     fn_checksum checksum = nullptr;
     fn_bound bound = nullptr;
     fn_combine crc_combine = nullptr, adler_combine = nullptr;
     fn_strerror strerror_ = nullptr;
     fn_set2 set_search = nullptr;
     fn_set1 set_min_lazy = nullptr;
+    fn_set2 set_long_match = nullptr;
     int (*set_split)(uint64_t) = nullptr;
 } g;
 
@@ -80,6 +82,7 @@ napi_value Init_(napi_env env, napi_callback_info info) {
     g.deflate_batch = (fn_deflate_batch)dlsym(h, "zgpu_deflate_batch");
     g.batch_begin = (fn_batch_begin)dlsym(h, "zgpu_deflate_batch_begin");
     g.batch_finish = (fn_batch_finish)dlsym(h, "zgpu_deflate_batch_finish");
+    g.job_release = (void (*)(void *))dlsym(h, "zgpu_job_release");
     g.checksum = (fn_checksum)dlsym(h, "zgpu_checksum");
     g.bound = (fn_bound)dlsym(h, "zgpu_deflate_bound");
     g.crc_combine = (fn_combine)dlsym(h, "zgpu_crc32_combine");
@@ -87,9 +90,10 @@ napi_value Init_(napi_env env, napi_callback_info info) {
     g.strerror_ = (fn_strerror)dlsym(h, "zgpu_strerror");
     g.set_search = (fn_set2)dlsym(h, "zgpu_set_search");
     g.set_min_lazy = (fn_set1)dlsym(h, "zgpu_set_min_lazy");
+    g.set_long_match = (fn_set2)dlsym(h, "zgpu_set_long_match");
     g.set_split = (int (*)(uint64_t))dlsym(h, "zgpu_set_split");
-    if (!g.deflate_batch || !g.batch_begin || !g.batch_finish || !g.checksum || !g.bound || !g.crc_combine || !g.adler_combine || !g.strerror_ ||
-        !g.set_search || !g.set_min_lazy || !g.set_split) {
+    if (!g.deflate_batch || !g.batch_begin || !g.batch_finish || !g.job_release || !g.checksum || !g.bound || !g.crc_combine || !g.adler_combine || !g.strerror_ ||
+        !g.set_search || !g.set_min_lazy || !g.set_split || !g.set_long_match) {
         dlclose(h);
         napi_throw_error(env, nullptr, "libzgpu.so lacks an expected symbol");
         return nullptr;
@@ -179,14 +183,22 @@ napi_value DeflateBatch(napi_env env, napi_callback_info info) {
         int rc = g.batch_begin(src, in_off.data(), n, ctype, lazy,
                                flags | (want_crc ? 16u : 0u) | (want_adler ? 32u : 0u), &job, &total);
         if (rc) return throw_zgpu(env, "zgpu_deflate_batch_begin", rc);
+        // from here to batch_finish (which releases the job itself, also when it fails) every way out
+        // releases the job: the compressed bytes it holds live in device memory
+        struct JobGuard {
+            void *job;
+            ~JobGuard() {
+                if (job) g.job_release(job);
+            }
+        } guard{job};
         flat.reset();
         void *ab_data = nullptr;
         napi_value ab;
         if (napi_create_arraybuffer(env, total, &ab_data, &ab) != napi_ok) {
-            g.batch_finish(job, nullptr, 0, nullptr, nullptr, nullptr);  // releases the job
             napi_throw_error(env, nullptr, "cannot allocate the output ArrayBuffer");
             return nullptr;
         }
+        guard.job = nullptr;
         rc = g.batch_finish(job, (uint8_t *)ab_data, total, out_off.data(), want_crc ? crc.data() : nullptr,
                             want_adler ? adler.data() : nullptr);
         if (rc) return throw_zgpu(env, "zgpu_deflate_batch_finish", rc);
@@ -278,6 +290,19 @@ napi_value SetSearch(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 
+napi_value SetLongMatch(napi_env env, napi_callback_info info) {
+    if (!need_lib(env)) return nullptr;
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    int32_t a = 0, b = 1;
+    if (argc > 0) NAPI_OK(napi_get_value_int32(env, argv[0], &a));
+    if (argc > 1) NAPI_OK(napi_get_value_int32(env, argv[1], &b));
+    int rc = g.set_long_match(a, b);
+    if (rc) return throw_zgpu(env, "zgpu_set_long_match", rc);
+    return nullptr;
+}
+
 napi_value SetMinLazy(napi_env env, napi_callback_info info) {
     if (!need_lib(env)) return nullptr;
     size_t argc = 1;
@@ -312,6 +337,7 @@ napi_value ModuleInit(napi_env env, napi_value exports) {
         {"adler32Combine", nullptr, Adler32Combine, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"deflateBound", nullptr, DeflateBound, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setSearch", nullptr, SetSearch, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setLongMatch", nullptr, SetLongMatch, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setMinLazy", nullptr, SetMinLazy, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setSplit", nullptr, SetSplit, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     };

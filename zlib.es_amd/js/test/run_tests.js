@@ -6,7 +6,7 @@
 // does for cross-implementation conformance.  Needs a GPU.
 const assert = require('assert');
 const nodeZlib = require('zlib');
-const { Zlib, deflateChunked, gzipChunked } = require('../zlib_gpu.js');
+const { Zlib, deflateChunked, gzipChunked, zlibChunked } = require('../zlib_gpu.js');
 const H = require('./helpers.js');
 
 const size = 76543; // test/browser.es/zlib-test.js:7
@@ -36,6 +36,9 @@ it('CRC32 / Adler32 known answers', () => {
 	assert.strictEqual(Zlib.CRC32.update(d.subarray(1000), Zlib.CRC32.calc(d.subarray(0, 1000))), H.crc32(d));
 	assert.strictEqual(Zlib.Adler32.update(Zlib.Adler32.mkHash(d.subarray(0, 1000)), d.subarray(1000)), H.adler32(d));
 	assert.strictEqual(Zlib.CRC32.calc(d, 10, 500), H.crc32(d.subarray(10, 510)));
+	// a position without a length runs to the end of the array (src/crc32.js:25-29)
+	assert.strictEqual(Zlib.CRC32.update(d, Zlib.CRC32.calc(d.subarray(0, 777)), 777), H.crc32(d));
+	assert.strictEqual(Zlib.RawDeflate.CompressionType.UNCOMPRESSED, Zlib.RawDeflate.CompressionType.NONE);
 });
 
 // ---- zlib-test.js:15-84 / raw-inflate-test.js:25-108 ----
@@ -180,6 +183,29 @@ it('gzipChunked: one member, many chunks compressed side by side', () => {
 	assert.ok(H.equal(nodeZlib.inflateRawSync(alone), data.subarray(65536, 131072)));
 	const size = (r) => r.parts.reduce((s, p) => s + p.length, 0);
 	assert.ok(size(d) <= size(ind));
+});
+
+it('zlibChunked: one zlib stream, chunks compressed side by side, Adler-32 by combine', () => {
+	const data = H.makeText(2 * 1048576 + 777, 9);
+	for (const ct of [CT.FIXED, CT.DYNAMIC]) {
+		const zs = zlibChunked(data, { chunkSize: 262144, compressionType: ct });
+		assert.strictEqual(zs[0], 0x78);
+		assert.strictEqual(((zs[0] << 8) | zs[1]) % 31, 0);
+		assert.ok(H.equal(nodeZlib.inflateSync(Buffer.from(zs)), data)); // verifies the Adler-32 trailer
+	}
+	assert.ok(H.equal(nodeZlib.inflateSync(Buffer.from(zlibChunked(new Uint8Array(0)))), new Uint8Array(0)));
+});
+it('Zip: extra field is written to both headers', () => {
+	const zip = new Zlib.Zip();
+	const extra = new Uint8Array([0x55, 0x54, 0x03, 0x00, 0x01, 0x02, 0x03]);
+	zip.addFile(H.makeText(5000, 2), { filename: new Uint8Array(Buffer.from('with-extra')), extraField: extra });
+	zip.addFile(H.makeText(3000, 3), { filename: new Uint8Array(Buffer.from('plain')) });
+	const z = zip.compress();
+	assert.strictEqual(new DataView(z.buffer).getUint16(28, true), extra.length); // local header's extra length
+	assert.ok(H.equal(z.subarray(30 + 10, 30 + 10 + extra.length), extra));
+	const files = unzip(z);
+	assert.ok(H.equal(files['with-extra'], H.makeText(5000, 2)));
+	assert.ok(H.equal(files.plain, H.makeText(3000, 3)));
 });
 
 // ---- batch API ----

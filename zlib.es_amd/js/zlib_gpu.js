@@ -49,8 +49,9 @@ class CRC32 {
 		const a = asU8(data);
 		const p = typeof pos === 'number' ? pos : 0;
 		const l = typeof length === 'number' ? length : a.length;
-		const c = addon.checksum(a.subarray(p, p + l))[0];
-		return addon.crc32Combine(crc >>> 0, c, l) >>> 0;
+		const sub = a.subarray(p, p + l); // clamped to the array's end, as the combine below must be
+		const c = addon.checksum(sub)[0];
+		return addon.crc32Combine(crc >>> 0, c, sub.length) >>> 0;
 	}
 	static single(num, crc) {
 		// one table step, used by ZipCrypto key updates only (src/crc32.js:48-50)
@@ -118,7 +119,12 @@ class RawDeflate {
 	// them, test/browser.es/code-path-test.js:22-24); each hands its block to
 	// the GPU and appends the result after the bytes already in the output.
 	_gpuBlock(blockArray, ctype, isFinalBlock) {
-		const r = addon.deflateBatch([asU8(blockArray)], ctype, this.lazy | 0, isFinalBlock ? F_FINAL_EACH : F_SYNC_ALIGN, false, false);
+		// a container that needs the input's checksum (Deflate: Adler-32, Gzip: CRC-32) asks for it
+		// with the same engine call, so the input crosses PCIe once
+		const want = this._want || 0;
+		const r = addon.deflateBatch([asU8(blockArray)], ctype, this.lazy | 0, isFinalBlock ? F_FINAL_EACH : F_SYNC_ALIGN, want === 1, want === 2);
+		if (want === 1) this._crc32 = r.crc32[0];
+		if (want === 2) this._adler32 = r.adler32[0];
 		const body = r.outputs[0];
 		if (this.op === 0 && body.byteOffset === 0 && body.byteLength === body.buffer.byteLength) {
 			// nothing before it: the addon's buffer already is a view at byteOffset 0 of its own buffer
@@ -153,7 +159,8 @@ class RawDeflate {
 		return addon.deflateBatch(inputs.map(asU8), ct, o.lazy | 0, F_FINAL_EACH, false, false).outputs;
 	}
 }
-RawDeflate.CompressionType = { NONE: 0, FIXED: 1, DYNAMIC: 2, RESERVED: 3 };
+// UNCOMPRESSED: the bundle's alias of NONE (reference src/zlib.es.js:111-117)
+RawDeflate.CompressionType = { UNCOMPRESSED: 0, NONE: 0, FIXED: 1, DYNAMIC: 2, RESERVED: 3 };
 
 class Deflate {
 	// src/deflate.js:20-30
@@ -186,9 +193,10 @@ class Deflate {
 		let flg = flevel << 6;
 		flg |= 31 - ((cmf * 256 + flg) % 31);
 		output[pos++] = flg;
-		const adler = Adler32.mkHash(this.input);
 		this.rawDeflate.op = pos;
+		this.rawDeflate._want = 2; // Adler-32 of the input from the same call (src/deflate.js:83 is a separate pass)
 		const body = this.rawDeflate.compress();
+		const adler = this.rawDeflate._adler32 !== undefined ? this.rawDeflate._adler32 : Adler32.mkHash(this.input);
 		let pos2 = body.length;
 		const out = withTrailerRoom(body, pos2, 4);
 		out[pos2++] = (adler >> 24) & 0xff;
@@ -249,10 +257,11 @@ class Gzip {
 		this.deflateOptions.outputBuffer = output;
 		this.deflateOptions.outputIndex = head.length;
 		const rawdeflate = new RawDeflate(this.input, this.deflateOptions);
+		rawdeflate._want = 1; // CRC-32 of the input from the same call (src/gzip.js:117 is a separate pass)
 		const body = rawdeflate.compress();
 		let op2 = rawdeflate.op;
 		const out = withTrailerRoom(body, op2, 8);
-		const crc32 = CRC32.calc(this.input);
+		const crc32 = rawdeflate._crc32 !== undefined ? rawdeflate._crc32 : CRC32.calc(this.input);
 		out[op2++] = crc32 & 0xff;
 		out[op2++] = (crc32 >>> 8) & 0xff;
 		out[op2++] = (crc32 >>> 16) & 0xff;
@@ -349,8 +358,9 @@ class Zip {
 				for (let j = 12; j < len; ++j) buffer[j] = this.encode(key, buffer[j]);
 				file.buffer = buffer;
 			}
-			localFileSize += 30 + filenameLength + file.buffer.length;
-			centralDirectorySize += 46 + filenameLength + commentLength;
+			const extraLength = opt.extraField ? opt.extraField.length : 0;
+			localFileSize += 30 + filenameLength + extraLength + file.buffer.length;
+			centralDirectorySize += 46 + filenameLength + extraLength + commentLength;
 		}
 		const endOfCentralDirectorySize = 22 + (this.comment ? this.comment.length : 0);
 		const output = new Uint8Array(localFileSize + centralDirectorySize + endOfCentralDirectorySize);
@@ -358,7 +368,7 @@ class Zip {
 		for (const file of files) {
 			const opt = file.option;
 			const filenameLength = opt.filename ? opt.filename.length : 0;
-			const extraFieldLength = 0;
+			const extraFieldLength = opt.extraField ? opt.extraField.length : 0;
 			const commentLength = opt.comment ? opt.comment.length : 0;
 			const offset = op1;
 			for (let k = 0; k < 4; ++k) output[op1++] = Zip.LocalFileHeaderSignature[k];
@@ -403,6 +413,13 @@ class Zip {
 				output.set(opt.filename, op2);
 				op1 += filenameLength;
 				op2 += filenameLength;
+			}
+			// extra field after the name in both headers (src/zip.js:231-236)
+			if (opt.extraField) {
+				output.set(opt.extraField, op1);
+				output.set(opt.extraField, op2);
+				op1 += extraFieldLength;
+				op2 += extraFieldLength;
 			}
 			if (opt.comment) {
 				output.set(opt.comment, op2);
@@ -501,6 +518,31 @@ function gzipChunked(input, opt) {
 	return out;
 }
 
+// One zlib stream (RFC 1950 framing as src/deflate.js:44-99 writes it: 78 xx header, body,
+// big-endian Adler-32) whose body is made of chunks compressed side by side; the Adler-32 of the
+// whole input comes from the chunks' values by combine.
+function zlibChunked(input, opt) {
+	const o = opt || {};
+	const a = asU8(input);
+	const d = deflateChunked(a, o);
+	const ct = typeof o.compressionType === 'number' ? o.compressionType : 2;
+	const cmf = (7 << 4) | 8;
+	let flg = ct << 6;
+	flg |= 31 - ((cmf * 256 + flg) % 31);
+	let total = 2 + 4;
+	for (const p of d.parts) total += p.length;
+	const out = new Uint8Array(total);
+	out[0] = cmf;
+	out[1] = flg;
+	let op = 2;
+	for (const p of d.parts) {
+		out.set(p, op);
+		op += p.length;
+	}
+	out.set([(d.adler32 >>> 24) & 0xff, (d.adler32 >>> 16) & 0xff, (d.adler32 >>> 8) & 0xff, d.adler32 & 0xff], op);
+	return out;
+}
+
 // compress side of the Node wrapper (reference node/exports.js:28-69,127-165):
 // deflateSync takes {deflateOption, noBuffer}; gzipSync ignores every option
 // but noBuffer; the callback forms run on the next tick and pass (error, data).
@@ -531,6 +573,6 @@ const gzip = nextTickForm(gzipSync);
 
 const Zlib = { RawDeflate, Deflate, Gzip, Zip, CRC32, Adler32 };
 module.exports = {
-	Zlib, RawDeflate, Deflate, Gzip, Zip, CRC32, Adler32, deflateChunked, gzipChunked,
+	Zlib, RawDeflate, Deflate, Gzip, Zip, CRC32, Adler32, deflateChunked, gzipChunked, zlibChunked,
 	deflate, deflateSync, gzip, gzipSync, addon,
 };
