@@ -50,6 +50,9 @@ size_t zo_rawdeflate(const uint8_t *in, size_t n, int ctype, int lazy,
 size_t zo_rawdeflate_heap32(const uint8_t *in, size_t n, int ctype, int lazy,
                             uint8_t *out, size_t cap, size_t out_index);
 size_t zo_deflate_bound(size_t n);
+/* n_units independent RawDeflate.compress() calls; returns the summed size */
+size_t zo_rawdeflate_many(const uint8_t *in, const uint64_t *off, size_t n_units, int ctype, int lazy,
+                          uint8_t *scratch, size_t scratch_cap);
 
 /* ---- containers: src/deflate.js:44-99, src/gzip.js:60-131 ---- */
 size_t zo_zlib_compress(const uint8_t *in, size_t n, int ctype, int lazy,

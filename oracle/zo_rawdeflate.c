@@ -712,3 +712,17 @@ size_t zo_rawdeflate_heap32(const uint8_t *in, size_t n, int ctype, int lazy, ui
                             size_t cap, size_t out_index) {
     return rawdeflate_impl(in, n, ctype, lazy, 0, out, cap, out_index);
 }
+
+/* Many independent units in one call (bench.py's all-core baseline leg: one call per thread and
+ * job keeps the interpreter out of the timing).  Returns the summed compressed size, or
+ * (size_t)-1 on failure.  scratch must hold zo_deflate_bound(largest unit) bytes. */
+size_t zo_rawdeflate_many(const uint8_t *in, const uint64_t *off, size_t n_units, int ctype, int lazy,
+                          uint8_t *scratch, size_t scratch_cap) {
+    size_t total = 0;
+    for (size_t i = 0; i < n_units; ++i) {
+        const size_t r = zo_rawdeflate(in + off[i], (size_t)(off[i + 1] - off[i]), ctype, lazy, scratch, scratch_cap, 0);
+        if (r == (size_t)-1) return r;
+        total += r;
+    }
+    return total;
+}

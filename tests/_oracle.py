@@ -47,6 +47,8 @@ def lib():
         f = getattr(L, name)
         f.restype = sz
         f.argtypes = [u8p, sz, i32, i32, u8p, sz, sz]
+    L.zo_rawdeflate_many.restype = sz
+    L.zo_rawdeflate_many.argtypes = [u8p, C.c_void_p, sz, i32, i32, u8p, sz]
     L.zo_deflate_bound.restype = sz
     L.zo_deflate_bound.argtypes = [sz]
     L.zo_zlib_compress.restype = sz
@@ -104,6 +106,18 @@ def rawdeflate(data, ctype=DYNAMIC, lazy=0, heap32=False, header=b""):
     if n == C.c_size_t(-1).value:
         raise RuntimeError("oracle rawdeflate failed")
     return out[:n].tobytes()
+
+
+def rawdeflate_many(flat, off, ctype=DYNAMIC, lazy=0):
+    """Summed compressed size of the units flat[off[i]:off[i+1]] (one C call; releases the GIL)."""
+    a = _arr(flat)
+    o = np.ascontiguousarray(off, dtype=np.uint64)
+    cap = lib().zo_deflate_bound(int((o[1:] - o[:-1]).max()) if o.size > 1 else 0) + 64
+    scratch = np.empty(cap, dtype=np.uint8)
+    r = lib().zo_rawdeflate_many(_ptr(a), o.ctypes.data, o.size - 1, ctype, lazy, scratch.ctypes.data, cap)
+    if r == C.c_size_t(-1).value:
+        raise RuntimeError("oracle rawdeflate_many failed")
+    return r
 
 
 def lz77(data, lazy=0):

@@ -241,6 +241,31 @@ struct DevBuf {
     T *as() const { return (T *)p; }
 };
 
+// the same for page-locked host memory (the device reads and writes it at full PCIe rate)
+struct HostBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return ZGPU_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            g_last_hip = (int)e;
+            p = nullptr;
+            return ZGPU_E_NOMEM;
+        }
+        cap = bytes;
+        return ZGPU_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 struct CkScratch {
     DevBuf seg_off, seg_crc, seg_adler, out2;
 };
@@ -490,6 +515,7 @@ const uint64_t kSubBytes = [] {
     const uint64_t v = e ? strtoull(e, nullptr, 10) : 0;
     return v >= (1ull << 20) ? v : (32ull << 20);
 }();
+constexpr uint64_t kStageMaxBytes = 3ull << 30;
 const int kSlots = [] {
     const char *e = getenv("ZGPU_SLOTS");
     const int v = e ? atoi(e) : 0;
@@ -504,7 +530,8 @@ struct Slot {
 struct HostCtx {
     std::mutex mu;  // one host-buffer call at a time per device
     Slot slot[kMaxSlots];
-    DevBuf d_res;  // compressed bytes of a batch until they are copied out (spare; a job takes it)
+    DevBuf d_res;   // compressed bytes of a batch until they are copied out (spare; a job takes it)
+    HostBuf h_res;  // ... and their page-locked landing place on the host for two-step calls
     DevBuf ck_res;
 };
 
@@ -519,6 +546,7 @@ void free_host_ctx(HostCtx *c) {
         if (s.st) (void)hipStreamDestroy(s.st);
     }
     c->d_res.release();
+    c->h_res.release();
     c->ck_res.release();
     delete c;
 }
@@ -581,6 +609,8 @@ struct zgpu_job {
         DeviceState *ds = nullptr;
         HostCtx *ctx = nullptr;
         DevBuf d_res;
+        HostBuf h_res;       // two-step calls: the compressed bytes come down while later sub-batches run
+        bool staged = false;
         uint64_t res_need = 0;
     };
     std::vector<Dev> devs;
@@ -648,6 +678,10 @@ int run_sub(BatchShared &S, size_t si, Slot &sl) {
     if (rc) return rc;
     memcpy(j->out_off.data() + sb.first, loc.data(), (size_t)n * sizeof(uint64_t));
     sb.out_bytes = loc[n];
+    if (dv.staged && sb.out_bytes) {
+        HIPCHK(hipMemcpyAsync((uint8_t *)dv.h_res.p + sb.res_off, d_out, sb.out_bytes, hipMemcpyDeviceToHost, sl.st));
+        HIPCHK(hipStreamSynchronize(sl.st));
+    }
     if (!S.out) return ZGPU_OK;
     uint64_t at;
     {
@@ -1154,11 +1188,16 @@ static int host_batch_compute(const uint8_t *in, const uint64_t *in_off, uint32_
                 j->subs.push_back(sb);
             }
             // result buffer: the device's spare one if it is large enough, else a new one
+            // a two-step call of moderate size also gets a page-locked host buffer: its sub-batches
+            // come down as they finish, and the second step is a copy between host buffers
+            const bool stage = !out && dv.res_need <= kStageMaxBytes;
             {
                 std::lock_guard<std::mutex> lk(g_mu);
                 std::swap(dv.d_res, dv.ctx->d_res);
+                if (stage) std::swap(dv.h_res, dv.ctx->h_res);
             }
             rc = dv.d_res.ensure(dv.res_need + 64);
+            if (rc == ZGPU_OK && stage) dv.staged = dv.h_res.ensure(dv.res_need + 64) == ZGPU_OK;
         }
     } catch (const std::bad_alloc &) {
         rc = ZGPU_E_NOMEM;
@@ -1218,6 +1257,25 @@ static int host_batch_copy_out(zgpu_job *j, uint8_t *out) {
     }
     std::mutex mu;
     int rc = ZGPU_OK;
+    bool all_staged = true;
+    for (const zgpu_job::Dev &dv : j->devs) all_staged = all_staged && dv.staged;
+    if (all_staged) {
+        // everything already lies in page-locked host memory: plain copies, a few threads side by side
+        // (the caller's buffer is often fresh, and first-touch page faults are what they spend time on)
+        const int nth = a >= (64ull << 20) ? 4 : (a >= (4ull << 20) ? 2 : 1);
+        auto mover = [&](int part) {
+            for (size_t i = (size_t)part; i < j->subs.size(); i += (size_t)nth) {
+                const SubBatch &sb = j->subs[i];
+                if (sb.out_bytes)
+                    memcpy(out + at[i], (const uint8_t *)j->devs[sb.dev_index].h_res.p + sb.res_off, sb.out_bytes);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nth; ++t) th.emplace_back(mover, t);
+        mover(0);
+        for (auto &t : th) t.join();
+        return ZGPU_OK;
+    }
     auto worker = [&](int dev_index, int part, int parts) {
         zgpu_job::Dev &dv = j->devs[dev_index];
         hipStream_t st = dv.ctx->slot[part].st;
@@ -1302,6 +1360,17 @@ void zgpu_job_release(zgpu_job *j) {
             }
         }
         if (!kept && dv.d_res.p && hipSetDevice(dv.device) == hipSuccess) dv.d_res.release();
+        if (dv.h_res.p) {
+            bool kept_h = false;
+            if (dv.ctx) {
+                std::lock_guard<std::mutex> lk(g_mu);
+                if (dv.ctx->h_res.cap < dv.h_res.cap) {
+                    std::swap(dv.ctx->h_res, dv.h_res);
+                    kept_h = dv.h_res.p == nullptr;
+                }
+            }
+            if (!kept_h) dv.h_res.release();
+        }
     }
     if (have_cur) (void)hipSetDevice(cur);
     --g_live;
