@@ -92,16 +92,15 @@ constexpr uint32_t L_TOTAL = L_SCR + SCR_BYTES;
 static_assert(L_TOTAL <= 163840, "LDS budget");
 
 // ---- LDS map of the emit kernel (bytes) --------------------------------------
-constexpr int EWG = 256;            // threads of an emit workgroup
-constexpr int ETOK = 4 * EWG;       // token slots per emission pass (a match takes two: at most 2 * EWG tokens of 48 bits)
 constexpr uint32_t E_FL = 0;                        // u32[288] + u32[32] block histograms
 constexpr uint32_t E_MISC = E_FL + 320 * 4;         // u32[64]
 constexpr uint32_t E_LLTAB = E_MISC + 64 * 4;       // u32[288] code | len<<16
 constexpr uint32_t E_DTAB = E_LLTAB + 288 * 4;      // u32[32]
-constexpr uint32_t E_STAGE = E_DTAB + 32 * 4;       // u32[STAGE_WORDS] bit staging
-constexpr int STAGE_WORDS = 1024;                   // >= header + (ETOK / 2) * 48 / 32 + carry
-static_assert(STAGE_WORDS >= 160 + (ETOK / 2) * 48 / 32 + 2, "staging capacity");
-constexpr uint32_t E_HUF = E_STAGE + STAGE_WORDS * 4;  // Huffman build scratch
+constexpr uint32_t E_STAGE = E_DTAB + 32 * 4;       // u32[stage_words] bit staging
+// staging words for nt threads per unit: header (160) + (4 nt / 2) tokens of 48 bits + carry, rounded up
+constexpr int stage_words(int nt) { return (160 + (4 * nt / 2) * 48 / 32 + 2 + 127) / 128 * 128; }
+static_assert(stage_words(256) == 1024, "staging capacity of the workgroup variant");
+constexpr uint32_t E_HUF = E_STAGE + stage_words(256) * 4;  // Huffman build scratch (offset of the 256-thread variant)
 // Huffman build scratch map (bytes from E_HUF): the lit/len tree, then the
 // distance tree (reused for the code-length tree); once the lit/len and
 // distance codes exist, the run-length items of the header reuse the first.
@@ -112,6 +111,7 @@ constexpr uint32_t H_RLE = 0;      // u16[320] items: symbol | extra << 8
 constexpr uint32_t H_CLF = 640;    // u32[32] code-length symbol freqs
 constexpr uint32_t H_CLTAB = 768;  // u32[32]
 constexpr uint32_t E_TOTAL = E_HUF + H_END;
+constexpr uint32_t emit_lds_bytes(int nt) { return E_STAGE + (uint32_t)stage_words(nt) * 4 + H_END; }
 
 // misc words (search kernel: M_NTOK, M_OLDEST, M_ITEM.., M_NEXT..; emit kernel: M_SCAN, M_UNIT, M_NTOK, M_TMP, M_OVF)
 enum { M_SCAN = 0 /*[16]*/, M_UNIT = 32, M_NTOK = 34, M_TMP = 35, M_OVF = 36,
@@ -223,6 +223,23 @@ __device__ inline uint32_t block_scan_excl(uint32_t v, uint32_t *total, uint32_t
     __syncthreads();
     *total = tot;
     return wsum + x - v;
+}
+
+// the same for NT threads that share a unit: one wave needs no barrier and no LDS
+template <int NT>
+__device__ inline uint32_t group_scan_excl(uint32_t v, uint32_t *total, uint32_t *part) {
+    if constexpr (NT == 64) {
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t y = __shfl_up(x, d, 64);
+            if ((threadIdx.x & 63) >= d) x += y;
+        }
+        *total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+        return x - v;
+    } else {
+        return block_scan_excl<NT / 64>(v, total, part);
+    }
 }
 
 // Wave-to-wave hand-off through one LDS word.  The LDS executes a wave's
@@ -1378,20 +1395,34 @@ struct EParams {
     int ctype;
 };
 
-}  // namespace
+// barrier of the NT threads that share a unit: the workgroup's, or -- one wave per unit -- none
+// (a wave runs in lockstep and the LDS serves its requests in order; the compiler must keep them so)
+template <int NT>
+__device__ __forceinline__ void group_sync() {
+    if constexpr (NT == 64)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else
+        __syncthreads();
+}
 
-extern "C" __global__ void __launch_bounds__(EWG, 8)
-zgpu_emit_kernel(EParams P) {
-    __shared__ __align__(16) uint8_t lds[E_TOTAL];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// NT threads per unit: 256 (a workgroup; units of any size) or 64 (one wave per unit, four units
+// side by side in a workgroup: for small units the serial stretches of the code construction are
+// what takes the time, and more of them then run at once)
+template <int NT>
+__device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
+    constexpr int EWG = NT;                  // shadows the workgroup-wide constants above
+    constexpr int ETOK = 4 * NT;
+    constexpr int STAGE_WORDS = stage_words(NT);
+    constexpr uint32_t E_HUF = E_STAGE + (uint32_t)STAGE_WORDS * 4;
+    const int tid = threadIdx.x % NT, lane = tid & 63, wave = tid >> 6;
     uint32_t *fl = (uint32_t *)(lds + E_FL), *fd = fl + 288, *misc = (uint32_t *)(lds + E_MISC);
     uint32_t *lltab = (uint32_t *)(lds + E_LLTAB), *dtab = (uint32_t *)(lds + E_DTAB);
     uint32_t *stage = (uint32_t *)(lds + E_STAGE);
     for (;;) {
         if (tid == 0) misc[M_UNIT] = P.unit_first + atomicAdd(P.counter, 1u);
-        __syncthreads();
+        group_sync<NT>();
         const uint32_t u = misc[M_UNIT];
-        __syncthreads();
+        group_sync<NT>();
         if (u >= P.unit_end) break;
         const uint32_t n = (uint32_t)(P.in_off[u + 1] - P.in_off[u]);
         uint32_t *out32 = (uint32_t *)(P.out_tmp + P.slot_off[u]);
@@ -1408,7 +1439,7 @@ zgpu_emit_kernel(EParams P) {
             const uint32_t ntok = P.ntok[gb];
             const uint32_t bfinal = (blk + 1 == nblk && final_unit) ? 1u : 0u;
             for (int i = tid; i < 320; i += EWG) fl[i] = P.hist[(size_t)gb * 320 + i];
-            __syncthreads();
+            group_sync<NT>();
             // stage[] holds the unit's partial last word at [0] and is zero elsewhere
             BitW bw{stage, bitpos - base_word * 32};
             if (P.ctype == 2) {
@@ -1418,7 +1449,7 @@ zgpu_emit_kernel(EParams P) {
                 // holds only the end-of-block symbol gains literal 0, and the distance
                 // alphabet is topped up to two used symbols
                 if (tid == 0 && ntok < 2) fl[0] = 1;
-                if (wave == 1) {
+                if (wave == (NT == 64 ? 0 : 1)) {
                     const unsigned long long nz = __ballot(lane < 30 && fd[lane] != 0);
                     const int c = __builtin_popcountll(nz);
                     if (c < 2 && lane == 0) {
@@ -1426,12 +1457,13 @@ zgpu_emit_kernel(EParams P) {
                         fd[(c == 0 || (nz & 1ull)) ? 1 : 0] = 1;
                     }
                 }
-                __syncthreads();
+                group_sync<NT>();
                 // ---- sort keys (weight << 9 | symbol, unused = INF) ----
                 for (int i = tid; i < 288; i += EWG)
                     TL.niw[i] = (i < 286 && fl[i]) ? ((fl[i] << 9) | (uint32_t)i) : INF;
                 if (tid < 32) TD.niw[tid] = (tid < 30 && fd[tid]) ? ((fd[tid] << 9) | (uint32_t)tid) : INF;
-                __syncthreads();
+                group_sync<NT>();
+                if constexpr (NT == 256) {
                 // ---- rank sort: a key's rank is the number of smaller keys ----
                 uint32_t rk0 = 0, rk1 = 0, key0, key1 = INF;
                 {
@@ -1459,12 +1491,55 @@ zgpu_emit_kernel(EParams P) {
                 if (tid == 95) misc[M_TMP] = rk1;   // dist key 31
                 if (key0 != INF) TL.sorted[rk0] = key0;
                 if (key1 != INF) (tid < 32 ? TL.sorted : TD.sorted)[rk1] = key1;
-                __syncthreads();
+                } else {
+                    // one wave: the used symbols are packed first (a small unit uses few), then sorted
+                    // in registers when they fit a wave, else ranked against each other
+                    const unsigned long long lt = (1ull << lane) - 1ull;
+                    uint32_t *U = TL.rank;  // free until the tree is built
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        const uint32_t i = (uint32_t)c * 64 + (uint32_t)lane;
+                        const uint32_t key = i < 288 ? TL.niw[i] : INF;
+                        const unsigned long long mk = __ballot(key != INF);
+                        if (key != INF) U[m + (uint32_t)__builtin_popcountll(mk & lt)] = key;
+                        m += (uint32_t)__builtin_popcountll(mk);
+                    }
+                    group_sync<NT>();
+                    if (m <= 64) {
+                        uint32_t key = (uint32_t)lane < m ? U[lane] : INF;
+                        key = wave_sort64(key);
+                        if ((uint32_t)lane < m) TL.sorted[lane] = key;
+                    } else {
+                        const uint32_t m4 = (m + 3) & ~3u;
+                        if ((uint32_t)lane < m4 - m) U[m + lane] = INF;  // pad to whole uint4 reads
+                        group_sync<NT>();
+                        const uint4 *kp = (const uint4 *)U;
+                        for (uint32_t i = (uint32_t)lane; i < m; i += 64) {
+                            const uint32_t key = U[i];
+                            uint32_t rk = 0;
+                            for (uint32_t j = 0; j < m4 / 4; ++j) {
+                                const uint4 q = kp[j];
+                                rk += (q.x < key) + (q.y < key) + (q.z < key) + (q.w < key);
+                            }
+                            TL.sorted[rk] = key;
+                        }
+                    }
+                    uint32_t dk = lane < 32 ? TD.niw[lane] : INF;
+                    dk = wave_sort64(dk);
+                    if (lane < 32) TD.sorted[lane] = dk;
+                    const uint32_t md = (uint32_t)__builtin_popcountll(__ballot(dk != INF));  // all lanes vote
+                    if (lane == 0) {
+                        misc[M_NTOK] = m;
+                        misc[M_TMP] = md;
+                    }
+                }
+                group_sync<NT>();
                 const uint32_t mL = misc[M_NTOK], mD = misc[M_TMP];
                 // ---- the two trees, one wave each ----
                 if (wave == 0) wave_huffman<5>(TL, mL, 286, 15, lltab);
-                if (wave == 1) wave_huffman<1>(TD, mD, 30, 15, dtab);
-                __syncthreads();
+                if (wave == (NT == 64 ? 0 : 1)) wave_huffman<1>(TD, mD, 30, 15, dtab);
+                group_sync<NT>();
                 // ---- header (wave 0): HLIT/HDIST, run-length items, code-length code, bits ----
                 if (wave == 0) {
                     uint16_t *rle = (uint16_t *)(lds + E_HUF + H_RLE);
@@ -1681,9 +1756,9 @@ zgpu_emit_kernel(EParams P) {
                     misc[M_TMP] = bw.rel;
                 }
             }
-            __syncthreads();
+            group_sync<NT>();
             bitpos = base_word * 32 + misc[M_TMP];
-            __syncthreads();
+            group_sync<NT>();
             // ---- emit tokens: four slots per thread and pass ----
             // bits of a pass are OR-merged into the staging words at their prefix-sum
             // offsets; full words leave with coalesced stores and are cleared by the
@@ -1739,7 +1814,7 @@ zgpu_emit_kernel(EParams P) {
                 }
                 uint32_t total;
                 const uint32_t mine = sn[0] + sn[1] + sn[2] + sn[3];
-                const uint32_t off = block_scan_excl<EWG / 64>(mine, &total, misc + M_SCAN);
+                const uint32_t off = group_scan_excl<NT>(mine, &total, misc + M_SCAN);
                 uint32_t rel = bitpos + off - base_word * 32;
                 // neighbours that fit one 64-bit piece together go as one
                 uint64_t acc = 0;
@@ -1757,7 +1832,7 @@ zgpu_emit_kernel(EParams P) {
                     accn += sn[s4];
                 }
                 stage_or(rel, acc, accn);
-                __syncthreads();
+                group_sync<NT>();
                 bitpos += total;
                 const uint32_t full = (bitpos >> 5) - base_word;
                 if (base_word + full <= cap_words) {
@@ -1776,7 +1851,7 @@ zgpu_emit_kernel(EParams P) {
                 base_word += full;
                 // the two barriers of the next pass's prefix sum separate this from its ORs
             }
-            __syncthreads();
+            group_sync<NT>();
         }
         // ---- finish the unit: byte-align, or an empty stored block for a chunk that is
         // followed by more of the same stream ----
@@ -1818,8 +1893,22 @@ zgpu_emit_kernel(EParams P) {
             P.out_size[u] = bp >> 3;
             P.status[u] = ovf ? 1u : 0u;
         }
-        __syncthreads();
+        group_sync<NT>();
     }
+}
+
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(256, 8)
+zgpu_emit_kernel(EParams P) {
+    __shared__ __align__(16) uint8_t lds[emit_lds_bytes(256)];
+    emit_units<256>(P, lds);
+}
+// one wave per unit, four units per workgroup: chosen for rounds of small units
+extern "C" __global__ void __launch_bounds__(256, 4)
+zgpu_emit_small_kernel(EParams P) {
+    __shared__ __align__(16) uint8_t lds[4 * emit_lds_bytes(64)];
+    emit_units<64>(P, lds + (threadIdx.x >> 6) * emit_lds_bytes(64));
 }
 
 // ---- stored blocks (CompressionType.NONE; makeNocompressBlock rawdeflate.js:131-153)

@@ -314,7 +314,7 @@ struct zgpu_plan {
     uint32_t *d_crc() const { return b_crc.as<uint32_t>(); }
     uint32_t *d_adler() const { return b_adler.as<uint32_t>(); }
     uint32_t *d_counter() const { return b_counter.as<uint32_t>(); }
-    struct Round { uint32_t first, end; };
+    struct Round { uint32_t first, end; uint64_t max_bytes; };
     std::vector<Round> rounds;  // units whose tokens share the token buffer at one time
     std::vector<uint32_t> h_status;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -418,15 +418,17 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap_bytes = (free_b + p->b_tok.cap) / 3;
         if (const char *e = getenv("ZGPU_TOK_BYTES")) cap_bytes = strtoull(e, nullptr, 10);
         const uint64_t cap_tokens = cap_bytes / 2;
-        uint64_t used = 0;
+        uint64_t used = 0, round_max = 0;
         uint32_t first = 0;
         for (uint32_t i = 0; i < n_pieces; ++i) {
             const uint64_t n = pc_off[i + 1] - pc_off[i], need = unit_tok_cap(n);
             if (used && used + need > cap_tokens) {
-                p->rounds.push_back({first, i});
+                p->rounds.push_back({first, i, round_max});
                 first = i;
                 used = 0;
+                round_max = 0;
             }
+            if (n > round_max) round_max = n;
             tok_off[i] = used;
             used += need;
             if (used > tok_buf_tokens) tok_buf_tokens = used;
@@ -434,7 +436,7 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
             blk_first[i] = (uint32_t)n_blocks;
             n_blocks += unit_blocks(n);
         }
-        p->rounds.push_back({first, n_pieces});
+        p->rounds.push_back({first, n_pieces, round_max});
     }
     // ---- one blob for the tables the kernels read ----
     size_t off = 0;
@@ -516,6 +518,11 @@ const uint64_t kSubBytes = [] {
     return v >= (1ull << 20) ? v : (32ull << 20);
 }();
 constexpr uint64_t kStageMaxBytes = 3ull << 30;
+// rounds whose units are all at most this long take the wave-per-unit emit kernel (ZGPU_EMIT_SMALL_MAX tunes)
+const uint64_t kEmitSmallMax = [] {
+    const char *e = getenv("ZGPU_EMIT_SMALL_MAX");
+    return e ? strtoull(e, nullptr, 10) : (16ull << 10);
+}();
 const int kSlots = [] {
     const char *e = getenv("ZGPU_SLOTS");
     const int v = e ? atoi(e) : 0;
@@ -1007,8 +1014,14 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             E.unit_end = end;
             E.unit_final = p->d_final;
             E.ctype = p->ctype;
-            const uint32_t emax = (uint32_t)p->ds->cus * ZGPU_EMIT_WG_PER_CU;
-            hipLaunchKernelGGL(zgpu_emit_kernel, dim3(cnt < emax ? cnt : emax), dim3(256), 0, st, E);
+            if (p->rounds[r].max_bytes <= kEmitSmallMax) {
+                // small units: one wave per unit, four units per workgroup, four workgroups per CU
+                const uint32_t wgs = (cnt + 3) / 4, emax = (uint32_t)p->ds->cus * 4;
+                hipLaunchKernelGGL(zgpu_emit_small_kernel, dim3(wgs < emax ? wgs : emax), dim3(256), 0, st, E);
+            } else {
+                const uint32_t emax = (uint32_t)p->ds->cus * ZGPU_EMIT_WG_PER_CU;
+                hipLaunchKernelGGL(zgpu_emit_kernel, dim3(cnt < emax ? cnt : emax), dim3(256), 0, st, E);
+            }
         }
     }
     HIPCHK(hipGetLastError());
