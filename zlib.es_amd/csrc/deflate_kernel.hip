@@ -68,6 +68,22 @@ constexpr uint32_t SHARE_MIN = 16;  // matches at least this long offer their di
 constexpr int SHARE_ITERS = 6;      // distinct distances scored per wave ...
 constexpr int SHARE_ITERS_THOROUGH = 16;  // ... and when the walk goes on past the first capped candidate
 
+
+// ---- geometry of the search kernel ------------------------------------------------------------
+// The constants above describe the full-window variant: one 1024-thread workgroup per CU with a
+// 64 KiB ring and 32 Ki chain slots.  SearchCfg gathers what a variant may change; the kernel body
+// reads its geometry from the variant's SearchCfg only.
+struct CfgFull {  // 32 KiB window, one workgroup per CU
+    static constexpr int WG = 1024;
+    static constexpr int WG_PER_CU = 1;
+    static constexpr uint32_t RING = 65536, CHAIN = 32768, HBITS = 13, NSLOT = 64, NSLOT_E = 128, LAG = 48;
+};
+struct CfgHalf {  // 16 KiB ring halves: two workgroups per CU (the occupancy experiment)
+    static constexpr int WG = 1024;
+    static constexpr int WG_PER_CU = 2;
+    static constexpr uint32_t RING = 32768, CHAIN = 16384, HBITS = 11, NSLOT = 32, NSLOT_E = 64, LAG = 24;
+};
+
 constexpr uint32_t huf_scratch_bytes(uint32_t cap) { return 17 * cap + 128; }  // see HufS
 
 // ---- LDS map of the search kernel (bytes) ------------------------------------
@@ -140,6 +156,7 @@ struct Lds {
 
 // input bytes [lo, hi) of the unit -> ring (and the mirror of its first bytes);
 // lo is a multiple of 16.  `nthreads` threads with ids `t` cooperate.
+template <uint32_t RING>
 __device__ inline void load_ring(uint8_t *ring, const uint8_t *in, uint32_t lo, uint32_t hi, int t,
                                  int nthreads, bool aligned) {
     uint32_t done = lo;
@@ -196,6 +213,7 @@ __device__ inline uint32_t mlen16(v4u a, v4u b) {
 // walk of a few steps sees are then all worth comparing, which gives smaller output than keying
 // by three bytes (on text by 2-4 %) and shorter walks; matches of exactly three bytes are only
 // found where a four-byte chain happens to lead to them.
+template <uint32_t HBITS>
 __device__ inline uint32_t hash4(uint32_t w) {
     return (w * 0x9E3779B1u) >> (32 - HBITS);
 }
@@ -561,16 +579,31 @@ struct Params {
 // candidate is nice_length long or the chain budget ends -- with nice_length 258 and
 // a budget as long as the window that is the reference's exhaustive search
 // (src/rawdeflate.js:370-395: longest wins, the nearest among equals).
-template <bool THOROUGH>
+template <bool THOROUGH, class C>
 __device__ __forceinline__ void search_units(const Params &P) {
+    // the variant's geometry; these names shadow the full-window constants of the same name
+    constexpr int WG = C::WG;
+    constexpr uint32_t RING = C::RING, WMASK = C::CHAIN - 1, HBITS = C::HBITS;
+    constexpr uint32_t NSLOT = C::NSLOT, NSLOT_E = C::NSLOT_E, LAG = C::LAG;
+    constexpr uint32_t REFILL = RING / 4;  // ring refill granule
+    constexpr uint32_t MAXDIST = C::CHAIN - 64 * (LAG + AHEAD) - 128;  // window minus the span of in-flight items
+    constexpr uint32_t L_RING = 0, L_PREV = L_RING + RING + RING_PAD, L_HEAD = L_PREV + 2 * C::CHAIN,
+                       L_FL = L_HEAD + (2u << HBITS), L_FD = L_FL + 288 * 4, L_MISC = L_FD + 32 * 4,
+                       L_SCR = L_MISC + 64 * 4;
+    constexpr uint32_t S_EXIT = 0, S_CNT = S_EXIT + NSLOT * 64 * 2, S_DONE = S_CNT + NSLOT * 64,
+                       S_ENT = S_DONE + NSLOT * 4, S_TOKB = S_ENT + NSLOT_E * 4, SCR_BYTES = S_TOKB + NSLOT_E * 4;
+    constexpr uint32_t L_TOTAL = L_SCR + SCR_BYTES;
+    static_assert(L_TOTAL * C::WG_PER_CU <= 163840, "LDS budget");
+    static_assert(REFILL >= LOOKAHEAD && NSLOT > LAG && NSLOT_E > 2 * LAG, "geometry");
+    // a refill may overwrite what lies a ring behind its end while the item LAG back still searches its window
+    static_assert(MAXDIST + 64 * LAG + 2 * REFILL <= RING, "ring holds the window");
     __shared__ __align__(16) uint8_t lds_raw[L_TOTAL];
-    Lds L{lds_raw};
     const int tid = threadIdx.x, lane = tid & 63;
-    uint8_t *ring = L.ring();
-    uint16_t *prevt = L.prev();
-    uint16_t *head = L.head();
-    uint32_t *fl = L.fl(), *fd = L.fd(), *misc = L.misc();
-    uint8_t *scr = L.scr();
+    uint8_t *ring = lds_raw + L_RING;
+    uint16_t *prevt = (uint16_t *)(lds_raw + L_PREV);
+    uint16_t *head = (uint16_t *)(lds_raw + L_HEAD);
+    uint32_t *fl = (uint32_t *)(lds_raw + L_FL), *fd = (uint32_t *)(lds_raw + L_FD), *misc = (uint32_t *)(lds_raw + L_MISC);
+    uint8_t *scr = lds_raw + L_SCR;
     PH_DECL;
 
     // The next unit's queue ticket and its entries of the unit tables are fetched by thread 0
@@ -637,7 +670,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 *(uint4 *)(ring + tid * 16) = pf;
                 if ((uint32_t)tid * 16u < RING_PAD) *(uint4 *)(ring + RING + tid * 16) = pf;
             }
-            load_ring(ring, in, pf_hi, hi, tid, WG, aligned);
+            load_ring<RING>(ring, in, pf_hi, hi, tid, WG, aligned);
             pf_hi = 0;
             if (tid == 0) {
                 misc[M_ITEM] = 0;
@@ -893,7 +926,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     uint32_t lo = p0 + REFILL, hi = p0 + 2 * REFILL;
                     if (hi > n) hi = n;
                     if (lo < hi) {
-                        load_ring(ring, in, lo, hi, lane, 64, aligned);
+                        load_ring<RING>(ring, in, lo, hi, lane, 64, aligned);
                         lds_publish(&misc[M_LOADED], hi);
                     }
                 }
@@ -912,7 +945,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     {
                         const uint32_t *w = (const uint32_t *)(ring + (ip & (RING - 1) & ~3u));
                         const uint32_t first4 = __builtin_amdgcn_alignbyte(w[1], w[0], ip & 3u);
-                        if (ip + 4 <= n) key = (hash4(first4) << 6) | (uint32_t)lane;  // all four bytes inside the unit
+                        if (ip + 4 <= n) key = (hash4<HBITS>(first4) << 6) | (uint32_t)lane;  // all four bytes inside the unit
                     }
                     key = wave_sort64(key);
                     const uint32_t kp = from_below(key, 0u), kn = from_above(key, 0xffffffffu);
@@ -1365,8 +1398,10 @@ __device__ __forceinline__ void search_units(const Params &P) {
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(WG) zgpu_deflate_kernel(Params P) { search_units<false>(P); }
-extern "C" __global__ void __launch_bounds__(WG) zgpu_deflate_thorough_kernel(Params P) { search_units<true>(P); }
+extern "C" __global__ void __launch_bounds__(1024) zgpu_deflate_kernel(Params P) { search_units<false, CfgFull>(P); }
+extern "C" __global__ void __launch_bounds__(1024) zgpu_deflate_thorough_kernel(Params P) { search_units<true, CfgFull>(P); }
+// the occupancy experiment: half the window, two workgroups (32 waves) per CU, 64 registers per lane
+extern "C" __global__ void __launch_bounds__(1024, 8) zgpu_deflate_half_kernel(Params P) { search_units<false, CfgHalf>(P); }
 
 namespace {
 

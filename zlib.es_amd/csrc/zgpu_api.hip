@@ -305,6 +305,12 @@ struct zgpu_plan {
     uint64_t *d_in_off = nullptr, *d_slot_off = nullptr, *d_tok_off = nullptr, *d_unit_in_off = nullptr;
     uint32_t *d_blk_first = nullptr, *d_prime = nullptr, *d_first_piece = nullptr;
     uint8_t *d_final = nullptr;
+    // per-unit checksums of long units: the units cut into segments of at most ZGPU_CK_SEG bytes
+    // (so that many workgroups share a long unit), folded per unit afterwards
+    uint32_t n_segs = 0;               // 0: every unit is its own segment
+    uint64_t *d_seg_off = nullptr;     // n_segs + 1
+    uint32_t *d_first_seg = nullptr;   // n_units + 1
+    DevBuf b_seg_crc, b_seg_adler;
     // results and workspace
     DevBuf b_out_off, b_unit_out_off, b_out_size, b_status, b_crc, b_adler, b_counter, b_tok, b_hist, b_ntok, b_out_tmp;
     uint64_t *d_out_off() const { return b_out_off.as<uint64_t>(); }
@@ -322,10 +328,38 @@ struct zgpu_plan {
     bool pooled = false;  // owned by a device's host context (not counted as a caller's live plan)
     void release_buffers() {
         for (DevBuf *b : {&d_tab, &b_out_off, &b_unit_out_off, &b_out_size, &b_status, &b_crc, &b_adler, &b_counter, &b_tok,
-                          &b_hist, &b_ntok, &b_out_tmp})
+                          &b_hist, &b_ntok, &b_out_tmp, &b_seg_crc, &b_seg_adler})
             b->release();
     }
 };
+
+// per-unit CRC-32 / Adler-32 from the values of a unit's segments (one thread per unit; same sums as above)
+extern "C" __global__ void __launch_bounds__(256)
+zgpu_unit_fold_kernel(const uint64_t *seg_off, const uint32_t *first_seg, const uint32_t *seg_crc,
+                      const uint32_t *seg_adler, uint32_t n_units, uint32_t *crc_out, uint32_t *adler_out) {
+    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_units) return;
+    const uint32_t M = 65521u;
+    const uint32_t s0 = first_seg[u], s1 = first_seg[u + 1];
+    const uint64_t end = seg_off[s1];
+    uint32_t crc = 0;
+    unsigned long long a1 = 0, a2 = 0;
+    for (uint32_t i = s0; i < s1; ++i) {
+        const uint64_t after = end - seg_off[i + 1];
+        uint32_t r = 0x80000000u, sq = 0x00800000u;
+        for (uint64_t e = after; e; e >>= 1) {
+            if (e & 1) r = gf_mul(r, sq);
+            sq = gf_mul(sq, sq);
+        }
+        crc ^= gf_mul(seg_crc[i], r);
+        const uint32_t a = seg_adler[i];
+        const unsigned long long d1 = ((a & 0xffffu) + M - 1) % M;
+        a1 += d1;
+        a2 += (a >> 16) + d1 * (after % M) % M;
+    }
+    crc_out[u] = crc;
+    adler_out[u] = (uint32_t)((a2 % M) << 16 | (1 + a1) % M);
+}
 
 namespace {
 uint64_t unit_blocks(uint64_t n) { return n ? (n + ZGPU_BLOCK_BYTES - 1) / ZGPU_BLOCK_BYTES : 1; }
@@ -438,6 +472,29 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
         }
         p->rounds.push_back({first, n_pieces, round_max});
     }
+    // ---- checksum segments (only when a unit is longer than a segment) ----
+    std::vector<uint64_t> seg_off;
+    std::vector<uint32_t> first_seg;
+    p->n_segs = 0;
+    if (flags & (ZGPU_F_WANT_CRC | ZGPU_F_WANT_ADLER)) {
+        bool long_unit = false;
+        for (uint32_t i = 0; i < n_units && !long_unit; ++i) long_unit = in_off[i + 1] - in_off[i] > ZGPU_CK_SEG;
+        if (long_unit) {
+            for (uint32_t i = 0; i < n_units; ++i) {
+                first_seg.push_back((uint32_t)seg_off.size());
+                const uint64_t o = in_off[i], n = in_off[i + 1] - o;
+                uint64_t k = 0;
+                do {
+                    seg_off.push_back(o + k);
+                    k += ZGPU_CK_SEG;
+                } while (k < n);
+                if (seg_off.size() > 0x7fffffffull) return ZGPU_E_TOOBIG;
+            }
+            first_seg.push_back((uint32_t)seg_off.size());
+            p->n_segs = (uint32_t)seg_off.size();
+            seg_off.push_back(in_off[n_units]);
+        }
+    }
     // ---- one blob for the tables the kernels read ----
     size_t off = 0;
     auto place = [&](size_t bytes) {
@@ -449,7 +506,9 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
                  o_tok = place((size_t)n_pieces * 8), o_blk = place((size_t)n_pieces * 4),
                  o_prime = place((size_t)n_pieces * 4), o_final = place((size_t)n_pieces),
                  o_uin = place(p->split ? (size_t)(n_units + 1) * 8 : 0),
-                 o_fp = place(p->split ? (size_t)(n_units + 1) * 4 : 0);
+                 o_fp = place(p->split ? (size_t)(n_units + 1) * 4 : 0),
+                 o_seg = place(p->n_segs ? (size_t)(p->n_segs + 1) * 8 : 0),
+                 o_fseg = place(p->n_segs ? (size_t)(n_units + 1) * 4 : 0);
     p->h_tab.resize(off);
     uint8_t *h = p->h_tab.data();
     memcpy(h + o_in, pc_off.data(), (size_t)(n_pieces + 1) * 8);
@@ -461,6 +520,10 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
     if (p->split) {
         memcpy(h + o_uin, in_off, (size_t)(n_units + 1) * 8);
         memcpy(h + o_fp, first_piece.data(), (size_t)(n_units + 1) * 4);
+    }
+    if (p->n_segs) {
+        memcpy(h + o_seg, seg_off.data(), (size_t)(p->n_segs + 1) * 8);
+        memcpy(h + o_fseg, first_seg.data(), (size_t)(n_units + 1) * 4);
     }
     int rc;
 #define ENS(buf, bytes)                        \
@@ -479,6 +542,10 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
         ENS(p->b_ntok, (size_t)n_blocks * 4);
     }
     if (p->split) ENS(p->b_unit_out_off, (size_t)(n_units + 1) * 8);
+    if (p->n_segs) {
+        ENS(p->b_seg_crc, (size_t)p->n_segs * 4);
+        ENS(p->b_seg_adler, (size_t)p->n_segs * 4);
+    }
 #undef ENS
     uint8_t *d = p->d_tab.as<uint8_t>();
     p->d_in_off = (uint64_t *)(d + o_in);
@@ -489,6 +556,8 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
     p->d_final = d + o_final;
     p->d_unit_in_off = (uint64_t *)(d + o_uin);
     p->d_first_piece = (uint32_t *)(d + o_fp);
+    p->d_seg_off = (uint64_t *)(d + o_seg);
+    p->d_first_seg = (uint32_t *)(d + o_fseg);
     if (async) {
         // pageable source: the runtime has taken the bytes when the call returns
         HIPCHK(hipMemcpyAsync(d, h, off, hipMemcpyHostToDevice, st));
@@ -518,6 +587,13 @@ const uint64_t kSubBytes = [] {
     return v >= (1ull << 20) ? v : (32ull << 20);
 }();
 constexpr uint64_t kStageMaxBytes = 3ull << 30;
+// the search kernel's half-window variant (two workgroups per CU) serves rounds of units of at most 16 KiB;
+// ZGPU_HALF_WINDOW=1 / 0 forces it on / off for measurements
+const int kHalfWindow = [] {
+    const char *e = getenv("ZGPU_HALF_WINDOW");
+    return e ? (e[0] == '1' ? 1 : 0) : -1;
+}();
+constexpr uint64_t kHalfWindowMax = 16384;
 // rounds whose units are all at most this long take the wave-per-unit emit kernel (ZGPU_EMIT_SMALL_MAX tunes)
 const uint64_t kEmitSmallMax = [] {
     const char *e = getenv("ZGPU_EMIT_SMALL_MAX");
@@ -992,8 +1068,13 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             P.fan = p->knobs.fan;
             P.unit_prime = p->d_prime;
             P.prof = g_prof;
-            const int sgrid = (int)(cnt < (uint32_t)p->ds->cus ? cnt : (uint32_t)p->ds->cus);
-            if (p->knobs.nice > 32)
+            int sgrid = (int)(cnt < (uint32_t)p->ds->cus ? cnt : (uint32_t)p->ds->cus);
+            if ((kHalfWindow == 1 || (kHalfWindow < 0 && p->rounds[r].max_bytes <= kHalfWindowMax)) && p->knobs.nice <= 32) {
+                // units that fit half a window lose nothing to it: two workgroups per CU, 32 waves
+                // (ZGPU_HALF_WINDOW=1 forces the variant for any unit size, =0 never takes it)
+                sgrid = (int)(cnt < 2 * (uint32_t)p->ds->cus ? cnt : 2 * (uint32_t)p->ds->cus);
+                hipLaunchKernelGGL(zgpu_deflate_half_kernel, dim3(sgrid), dim3(1024), 0, st, P);
+            } else if (p->knobs.nice > 32)
                 hipLaunchKernelGGL(zgpu_deflate_thorough_kernel, dim3(sgrid), dim3(1024), 0, st, P);
             else
                 hipLaunchKernelGGL(zgpu_deflate_kernel, dim3(sgrid), dim3(1024), 0, st, P);
@@ -1038,10 +1119,21 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
         hipLaunchKernelGGL(zgpu_unit_offsets_kernel, dim3(p->n_units / 256 + 1), dim3(256), 0, st, p->d_out_off(),
                            p->d_first_piece, p->d_unit_out_off(), p->n_units);
     if (p->flags & (ZGPU_F_WANT_CRC | ZGPU_F_WANT_ADLER)) {
-        int grid = p->n_units < (uint32_t)p->ds->cus * 8 ? (int)p->n_units : p->ds->cus * 8;
-        hipLaunchKernelGGL(zgpu_checksum_kernel, dim3(grid), dim3(ZGPU_CK_THREADS), 0, st,
-                           (const uint8_t *)d_in, p->split ? p->d_unit_in_off : p->d_in_off, p->n_units,
-                           p->ds->d_tables, p->d_crc(), p->d_adler());
+        if (p->n_segs) {
+            // long units: segments over many workgroups, then one fold per unit
+            int grid = p->n_segs < (uint32_t)p->ds->cus * 8 ? (int)p->n_segs : p->ds->cus * 8;
+            hipLaunchKernelGGL(zgpu_checksum_kernel, dim3(grid), dim3(ZGPU_CK_THREADS), 0, st, (const uint8_t *)d_in,
+                               p->d_seg_off, p->n_segs, p->ds->d_tables, p->b_seg_crc.as<uint32_t>(),
+                               p->b_seg_adler.as<uint32_t>());
+            hipLaunchKernelGGL(zgpu_unit_fold_kernel, dim3(p->n_units / 256 + 1), dim3(256), 0, st, p->d_seg_off,
+                               p->d_first_seg, p->b_seg_crc.as<uint32_t>(), p->b_seg_adler.as<uint32_t>(), p->n_units,
+                               p->d_crc(), p->d_adler());
+        } else {
+            int grid = p->n_units < (uint32_t)p->ds->cus * 8 ? (int)p->n_units : p->ds->cus * 8;
+            hipLaunchKernelGGL(zgpu_checksum_kernel, dim3(grid), dim3(ZGPU_CK_THREADS), 0, st,
+                               (const uint8_t *)d_in, p->split ? p->d_unit_in_off : p->d_in_off, p->n_units,
+                               p->ds->d_tables, p->d_crc(), p->d_adler());
+        }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(p->ev[3], st));
