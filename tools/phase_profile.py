@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import zlib_es_amd as z  # noqa: E402
 
+EPHASES = ["queue", "hist", "sort", "treeL", "treeD", "rle", "treeCL", "hdrbits", "tokens", "finish"]
 PHASES = ["load", "blkwait", "deep", "fan", "-", "-", "-", "emit-tok", "lag+ld", "sort", "linkwait", "link", "pass1", "pass2", "prep", "parsewait"]
 
 
@@ -25,7 +26,7 @@ def run(name, data, nu, ub, ctype, lazy):
     in_off = np.arange(nu + 1, dtype=np.uint64) * np.uint64(ub)
     plan = z.Plan(in_off, ctype, lazy, 1)
     out = torch.empty(plan.out_bound + 64, dtype=torch.uint8, device="cuda")
-    prof = np.zeros(16, dtype=np.uint64)
+    prof = np.zeros(32, dtype=np.uint64)
     L.zgpu_prof_read(prof.ctypes.data, 1)
     plan.run(data.data_ptr(), out.data_ptr(), out.numel(), None)
     torch.cuda.synchronize()
@@ -37,11 +38,13 @@ def run(name, data, nu, ub, ctype, lazy):
     L.zgpu_prof_read(prof.ctypes.data, 1)
     off, _, _ = plan.fetch()
     nbytes = nu * ub
-    per = prof.astype(np.float64) / nbytes
+    per = prof[:16].astype(np.float64) / nbytes
+    eper = prof[16:].astype(np.float64) / nu  # emit: cycles per unit
     sm, em = plan.phase_ms()
     print("%-8s %7.2f GB/s (search %.2f ms, emit %.2f ms) ratio %.4f | search cyc/B: %s | total %.1f" % (
         name, nbytes / dt / 1e9, sm, em, int(off[-1]) / nbytes,
         " ".join("%s=%.1f" % (p, v) for p, v in zip(PHASES, per) if p != "-"), per.sum()), flush=True)
+    print("         emit cycles/unit: %s | total %.0f" % (" ".join("%s=%.0f" % (p, v) for p, v in zip(EPHASES, eper)), eper.sum()), flush=True)
 
 
 def main():
@@ -51,7 +54,7 @@ def main():
     if "CHAIN" in os.environ:  # default: the library's own search depth
         z.set_search(int(os.environ["CHAIN"]), int(os.environ.get("NICE", "32")))
     dev = torch.device("cuda")
-    full = bench.gen_units(20 * 512, ub, 7, dev).view(-1, ub)
+    full = bench.gen_units(int(os.environ.get("GEN", 20 * 512)), ub, 7, dev).view(-1, ub)
     kinds = {"text": (0, 10), "binary": (10, 15), "random": (15, 18), "lowent": (18, 20)}
     idx = torch.arange(full.shape[0], device=dev) % 20
     for name, (a, b) in kinds.items():

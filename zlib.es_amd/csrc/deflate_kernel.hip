@@ -78,10 +78,14 @@ struct CfgFull {  // 32 KiB window, one workgroup per CU
     static constexpr int WG_PER_CU = 1;
     static constexpr uint32_t RING = 65536, CHAIN = 32768, HBITS = 13, NSLOT = 64, NSLOT_E = 128, LAG = 48;
 };
+#ifndef ZGPU_HALF_HBITS
+#define ZGPU_HALF_HBITS 11
+#define ZGPU_HALF_WGS 2
+#endif
 struct CfgHalf {  // 16 KiB ring halves: two workgroups per CU (the occupancy experiment)
     static constexpr int WG = 1024;
-    static constexpr int WG_PER_CU = 2;
-    static constexpr uint32_t RING = 32768, CHAIN = 16384, HBITS = 11, NSLOT = 32, NSLOT_E = 64, LAG = 24;
+    static constexpr int WG_PER_CU = ZGPU_HALF_WGS;
+    static constexpr uint32_t RING = 32768, CHAIN = 16384, HBITS = ZGPU_HALF_HBITS, NSLOT = 32, NSLOT_E = 64, LAG = 24;
 };
 
 constexpr uint32_t huf_scratch_bytes(uint32_t cap) { return 17 * cap + 128; }  // see HufS
@@ -1428,6 +1432,7 @@ struct EParams {
     const uint8_t *unit_final; // n_units: 1 = the unit ends its stream (BFINAL), 0 = it ends with an empty stored block
     uint32_t unit_first, unit_end;
     int ctype;
+    unsigned long long *prof;  // diagnostic builds: 16 per-phase cycle sums of each unit's thread 0
 };
 
 // barrier of the NT threads that share a unit: the workgroup's, or -- one wave per unit -- none
@@ -1453,12 +1458,15 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
     uint32_t *fl = (uint32_t *)(lds + E_FL), *fd = fl + 288, *misc = (uint32_t *)(lds + E_MISC);
     uint32_t *lltab = (uint32_t *)(lds + E_LLTAB), *dtab = (uint32_t *)(lds + E_DTAB);
     uint32_t *stage = (uint32_t *)(lds + E_STAGE);
+    PH_DECL;
+    PH_START();
     for (;;) {
         if (tid == 0) misc[M_UNIT] = P.unit_first + atomicAdd(P.counter, 1u);
         group_sync<NT>();
         const uint32_t u = misc[M_UNIT];
         group_sync<NT>();
         if (u >= P.unit_end) break;
+        PH_END(0);
         const uint32_t n = (uint32_t)(P.in_off[u + 1] - P.in_off[u]);
         uint32_t *out32 = (uint32_t *)(P.out_tmp + P.slot_off[u]);
         const uint32_t cap_words = (uint32_t)((P.slot_off[u + 1] - P.slot_off[u]) >> 2);
@@ -1475,6 +1483,7 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
             const uint32_t bfinal = (blk + 1 == nblk && final_unit) ? 1u : 0u;
             for (int i = tid; i < 320; i += EWG) fl[i] = P.hist[(size_t)gb * 320 + i];
             group_sync<NT>();
+            PH_END(1);
             // stage[] holds the unit's partial last word at [0] and is zero elsewhere
             BitW bw{stage, bitpos - base_word * 32};
             if (P.ctype == 2) {
@@ -1570,11 +1579,14 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
                     }
                 }
                 group_sync<NT>();
+                PH_END(2);
                 const uint32_t mL = misc[M_NTOK], mD = misc[M_TMP];
                 // ---- the two trees, one wave each ----
                 if (wave == 0) wave_huffman<5>(TL, mL, 286, 15, lltab);
+                if (NT == 64) PH_END(3);
                 if (wave == (NT == 64 ? 0 : 1)) wave_huffman<1>(TD, mD, 30, 15, dtab);
                 group_sync<NT>();
+                PH_END(4);
                 // ---- header (wave 0): HLIT/HDIST, run-length items, code-length code, bits ----
                 if (wave == 0) {
                     uint16_t *rle = (uint16_t *)(lds + E_HUF + H_RLE);
@@ -1697,6 +1709,7 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
                         }
                     }
                     asm volatile("" ::: "memory");
+                    PH_END(5);
                     // ---- code-length code (19 symbols, 7 bits) ----
                     {
                         uint32_t f = lane < 19 ? clf[lane] : 0u;
@@ -1710,6 +1723,7 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
                         wave_huffman<1>(TD, mC, 19, 7, cltab);
                     }
                     asm volatile("" ::: "memory");
+                    PH_END(6);
                     // ---- header bits: every field is OR-merged into the staging words ----
                     const uint32_t hb = bitpos - base_word * 32;  // bit offset of the header in stage[]
                     auto put_bits = [&](uint32_t rel, uint32_t v, uint32_t nb) {
@@ -1794,6 +1808,7 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
             group_sync<NT>();
             bitpos = base_word * 32 + misc[M_TMP];
             group_sync<NT>();
+            PH_END(7);
             // ---- emit tokens: four slots per thread and pass ----
             // bits of a pass are OR-merged into the staging words at their prefix-sum
             // offsets; full words leave with coalesced stores and are cleared by the
@@ -1887,6 +1902,7 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
                 // the two barriers of the next pass's prefix sum separate this from its ORs
             }
             group_sync<NT>();
+            PH_END(8);
         }
         // ---- finish the unit: byte-align, or an empty stored block for a chunk that is
         // followed by more of the same stream ----
@@ -1929,7 +1945,9 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
             P.status[u] = ovf ? 1u : 0u;
         }
         group_sync<NT>();
+        PH_END(9);
     }
+    PH_FLUSH();
 }
 
 }  // namespace

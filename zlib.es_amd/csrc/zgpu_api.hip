@@ -952,14 +952,15 @@ int zgpu_last_hip_error(void) { return g_last_hip; }
 #ifdef ZGPU_PROFILE
 // Diagnostic build only (not part of include/zgpu.h): per-phase cycle sums of
 // thread 0 of every workgroup since the last reset.
-int zgpu_prof_read(unsigned long long *out8, int reset) {
+// out: 32 sums -- 16 of the search kernel, then 16 of the emit kernel (thread 0 of every unit's group)
+int zgpu_prof_read(unsigned long long *out32, int reset) {
     if (!g_prof) {
-        HIPCHK(hipMalloc(&g_prof, 128));
-        HIPCHK(hipMemset(g_prof, 0, 128));
+        HIPCHK(hipMalloc(&g_prof, 256));
+        HIPCHK(hipMemset(g_prof, 0, 256));
     }
     HIPCHK(hipDeviceSynchronize());
-    if (out8) HIPCHK(hipMemcpy(out8, g_prof, 128, hipMemcpyDeviceToHost));
-    if (reset) HIPCHK(hipMemset(g_prof, 0, 128));
+    if (out32) HIPCHK(hipMemcpy(out32, g_prof, 256, hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(hipMemset(g_prof, 0, 256));
     return ZGPU_OK;
 }
 #endif
@@ -1095,6 +1096,7 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             E.unit_end = end;
             E.unit_final = p->d_final;
             E.ctype = p->ctype;
+            E.prof = g_prof ? g_prof + 16 : nullptr;
             if (p->rounds[r].max_bytes <= kEmitSmallMax) {
                 // small units: one wave per unit, four units per workgroup, four workgroups per CU
                 const uint32_t wgs = (cnt + 3) / 4, emax = (uint32_t)p->ds->cus * 4;
