@@ -40,7 +40,8 @@ def main():
     tag = sys.argv[1]
     os.makedirs(DST, exist_ok=True)
     # kernel stats
-    for sub, name in (("stats", "bench_kernel_stats"), ("ckstats", "checksum_kernel_stats")):
+    for sub, name in (("stats", "bench_kernel_stats"), ("ckstats", "checksum_kernel_stats"), ("zipstats", "zip_kernel_stats"),
+                      ("gzipstats", "gzip_kernel_stats")):
         p = find(sub, "kernel_stats.csv")
         if p:
             rows = list(csv.reader(open(p)))
@@ -48,7 +49,7 @@ def main():
                 csv.writer(f).writerows(rows)
     # counters, per launch
     out = {}
-    for sub in ("fetch", "write", "sq1", "sq2", "ckfetch"):
+    for sub in ("fetch", "write", "sq1", "sq2", "sq2_chain1", "sq2_fan0", "ckfetch"):
         agg, calls = counters(sub)
         for k, v in agg.items():
             if not k.startswith("zgpu_"):
@@ -97,6 +98,12 @@ def main():
                         "SIMD-cycles and the share of the SIMD's peak issue rate is 2 x SQ_INSTS_VALU / SQ_WAVE_CYCLES; "
                         "the wave_cycles_* shares split the waves' own time (SQ_ACTIVE_INST_ANY, SQ_WAIT_ANY, SQ_WAIT_INST_ANY)",
             }
+            # LDS bank-conflict cycles with parts of the search switched off: what the chain walk and the fan add
+            conf = {"default": q2["SQ_LDS_BANK_CONFLICT"]}
+            for sub, name in (("sq2_chain1", "max_chain_1"), ("sq2_fan0", "probe_fans_0")):
+                if sub in out and "zgpu_deflate_kernel" in out[sub]:
+                    conf[name] = out[sub]["zgpu_deflate_kernel"]["SQ_LDS_BANK_CONFLICT"]
+            traffic["lds"]["bank_conflict_cycles_by_setting"] = conf
         except KeyError:
             pass
         with open(os.path.join(DST, "traffic.json"), "w") as f:
