@@ -88,6 +88,8 @@ enum {
  * Optional: every entry point initialises lazily.  Device-pointer entry points
  * (zgpu_plan_*, zgpu_checksum_device*) always use the current device. */
 int zgpu_init(const int *device_ids, int n_devices);
+/* Number of visible devices (what zgpu_init's ids index), or a negative error. */
+int zgpu_device_count(void);
 /* Releases the per-device state (tables, staging buffers, streams).  Does
  * nothing while a plan or a job exists: destroy them first. */
 void zgpu_shutdown(void);

@@ -18,3 +18,12 @@ def pytest_configure(config):
 def golden():
     with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_opens_the_device_first():
+    """Tests hand torch device tensors to the library; torch must open the device before the library's own
+    first HIP call does (the other order leaves torch without a device in this image), whatever test runs first."""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()

@@ -28,7 +28,7 @@ def test_addon_loads_and_exports():
         pytest.fail("zgpu_addon.node missing: run __graft_entry__.build() / make -C zlib.es_amd/js")
     r = _node("const a=require('./zgpu_addon.node'); console.log(Object.keys(a).sort().join(','))")
     assert r.returncode == 0, r.stderr
-    assert r.stdout.strip() == "adler32Combine,checksum,crc32Combine,deflateBatch,deflateBound,init,setLongMatch,setMinLazy,setSearch,setSplit"
+    assert r.stdout.strip() == "adler32Combine,checksum,crc32Combine,deflateBatch,deflateBound,hostDevices,init,setLongMatch,setMinLazy,setSearch,setSplit"
 
 
 @needs_node
@@ -59,6 +59,30 @@ def test_no_cpu_fallback_in_js():
               "catch (e) { console.log('threw: ' + e.message); }")
     assert r.returncode == 0, r.stderr
     assert "threw" in r.stdout and "computed" not in r.stdout
+
+
+@pytest.mark.gpu
+@needs_node
+def test_named_devices_under_node():
+    """ZGPU_DEVICES=all hands every visible GPU to the library's batch split; the calls still give correct
+    streams (on a one-GPU box the list is [0])."""
+    env = dict(os.environ, ZGPU_DEVICES="all")
+    r = subprocess.run([NODE, "-e", """
+const z = require('./zlib_gpu.js'), zlib = require('zlib');
+const devs = z.addon.hostDevices();
+if (!Array.isArray(devs) || devs.length < 1) throw new Error('devices ' + JSON.stringify(devs));
+const n = 300, ub = 1 << 20, big = new Uint8Array(n * ub);            // 300 MiB: above the multi-device threshold
+let x = 7; for (let i = 0; i < big.length; ++i) { if ((i & 3) === 0) x = (Math.imul(x, 1664525) + 1013904223) >>> 0; big[i] = 97 + ((x >>> (8 * (i & 3))) & 7); }
+const views = []; for (let i = 0; i < n; ++i) views.push(big.subarray(i * ub, (i + 1) * ub));
+const outs = z.Zlib.RawDeflate.compressBatch(views, { compressionType: 2 });
+for (const i of [0, 1, 149, 150, 298, 299]) {
+  const back = zlib.inflateRawSync(Buffer.from(outs[i].buffer, outs[i].byteOffset, outs[i].length));
+  if (Buffer.compare(back, Buffer.from(big.buffer, i * ub, ub)) !== 0) throw new Error('unit ' + i);
+}
+console.log('ok ' + devs.join(','));
+"""], cwd=JS, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:] + "\n" + r.stderr[-2000:])
+    assert r.stdout.startswith("ok ")
 
 
 @pytest.mark.gpu

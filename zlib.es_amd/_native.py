@@ -17,7 +17,7 @@ F_FINAL_EACH, F_SYNC_ALIGN, F_FINAL_LAST, F_PRIME_WINDOW, F_WANT_CRC, F_WANT_ADL
 
 # every symbol include/zgpu.h declares
 SYMBOLS = [
-    "zgpu_init", "zgpu_shutdown", "zgpu_host_devices", "zgpu_partition_units", "zgpu_strerror", "zgpu_last_hip_error", "zgpu_set_search", "zgpu_set_split",
+    "zgpu_init", "zgpu_device_count", "zgpu_shutdown", "zgpu_host_devices", "zgpu_partition_units", "zgpu_strerror", "zgpu_last_hip_error", "zgpu_set_search", "zgpu_set_split",
     "zgpu_set_min_lazy", "zgpu_set_long_match",
     "zgpu_deflate_bound", "zgpu_deflate_batch", "zgpu_deflate_batch_begin", "zgpu_deflate_batch_finish",
     "zgpu_job_release", "zgpu_plan_create", "zgpu_plan_destroy",
@@ -52,6 +52,8 @@ def lib():
     L.zgpu_init.restype = i32
     L.zgpu_init.argtypes = [C.POINTER(i32), i32]
     L.zgpu_shutdown.restype = None
+    L.zgpu_device_count.restype = i32
+    L.zgpu_device_count.argtypes = []
     L.zgpu_host_devices.restype = i32
     L.zgpu_host_devices.argtypes = [vp, i32]
     L.zgpu_partition_units.restype = i32

@@ -364,19 +364,17 @@ __device__ inline uint32_t wl(uint32_t old, uint32_t val, uint32_t l) {
 struct HufS {          // LDS scratch of one tree, cap = alphabet size rounded up to 32
     uint32_t *sorted;  // [cap] keys (weight << 9 | symbol), ascending; m of them are real
     uint32_t *niw;     // [cap] weights of the internal nodes (sort keys before that)
-    uint16_t *cl;      // [cap] leaves consumed after merge step k
     uint16_t *parN;    // [cap] parent of internal node
     uint16_t *parL;    // [cap] parent of leaf (by sorted index)
     uint16_t *dep;     // [cap] depth of internal node
     uint32_t *blc;     // [32]  symbols per code length
     uint8_t *lens;     // [cap] code length per symbol
-    uint32_t *rank;    // [cap] sort ranks (aliases cl, parN)
+    uint32_t *rank;    // [cap] sort ranks (aliases parN and the two bytes per entry before it)
 };
 __device__ inline HufS huf_scratch(uint8_t *base, uint32_t cap) {
     HufS S;
     S.sorted = (uint32_t *)base;
     S.niw = (uint32_t *)(base + 4 * cap);
-    S.cl = (uint16_t *)(base + 8 * cap);
     S.parN = (uint16_t *)(base + 10 * cap);
     S.parL = (uint16_t *)(base + 12 * cap);
     S.dep = (uint16_t *)(base + 14 * cap);
@@ -396,61 +394,60 @@ __device__ void wave_huffman(const HufS &S, uint32_t m_in, uint32_t nsym, uint32
     const uint32_t INF = 0xffffffffu;
     for (uint32_t sy = lane; sy < nsym; sy += 64) S.lens[sy] = 0;
     if (lane < 32) S.blc[lane] = 0;
-    // ---- two-queue merge.  Leaves and internal nodes are each consumed in order, so a
-    // 64-entry register window per queue feeds the heads through readlane.  Produced
-    // nodes collect in a window register that is flushed to LDS every 64 nodes (with the
-    // count of leaves consumed so far, from which the parents follow); the node queue
-    // reads that register while it consumes from the window being produced.
+    // ---- two-queue merge, many steps per round.  Huffman's rule -- join the two lightest, leaves
+    // before nodes of equal weight, nodes in order of creation -- consumes leaves and nodes each in
+    // order.  Let t be the weight of the next node (the sum of the two lightest): every leaf and
+    // node that weighs at most t is consumed before any node made from now on (those weigh at
+    // least t and queue behind), so these items, in merged order, pair up (0,1), (2,3), ... exactly
+    // as the serial rule would pair them, and all the pairs of a round are independent.  A round
+    // looks at the next 32 leaves (lanes 0..31, ascending) and the next 32 nodes (lanes 63..32,
+    // i.e. descending by lane: together a bitonic sequence, sorted by one merge network), takes
+    // the prefix that weighs at most t, cuts it where a window ran out although its queue goes
+    // on (items behind the window could belong in between), and joins the pairs.  Keys are
+    // weight << 7 | tag with tag = window index for leaves and 64 + window index for nodes, which
+    // orders equal weights as the rule asks.
     {
-        uint32_t li = 0, ii = 0;
-        uint32_t lwin = lane < m ? S.sorted[lane] >> 9 : INF;  // leaves [li & ~63, +64)
-        uint32_t nwin = INF;                                   // nodes  [ii & ~63, +64), once flushed
-        uint32_t pwin = INF, cwin = 0;                         // nodes / leaf counts [k & ~63, +64)
-        uint32_t lhead = rl(lwin, 0), nhead = INF;
-        for (uint32_t k = 0; k + 1 < m; ++k) {
-            uint32_t w = 0;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                if (lhead <= nhead) {
-                    w += lhead;
-                    ++li;
-                    if ((li & 63u) == 0) lwin = li + lane < m ? S.sorted[li + lane] >> 9 : INF;
-                    lhead = rl(lwin, li & 63u);
-                } else {
-                    w += nhead;
-                    ++ii;
-                    // nodes at or beyond k do not exist yet: the production window holds INF there
-                    if ((ii >> 6) == (k >> 6)) {
-                        nhead = rl(pwin, ii & 63u);
-                    } else {
-                        if ((ii & 63u) == 0) nwin = S.niw[ii + lane];
-                        nhead = rl(nwin, ii & 63u);
-                    }
-                }
+        uint32_t li = 0, ii = 0, k = 0;  // leaves consumed, nodes consumed, nodes made (wave-uniform)
+        while (k + 1 < m) {
+            const uint32_t j = lane < 32 ? lane : 63 - lane;
+            uint32_t key = INF;
+            if (lane < 32) {
+                if (li + j < m) key = ((S.sorted[li + j] >> 9) << 7) | j;
+            } else {
+                if (ii + j < k) key = (S.niw[ii + j] << 7) | (64 + j);
             }
-            pwin = wl(pwin, w, k & 63u);
-            cwin = wl(cwin, li, k & 63u);
-            if (ii == k) nhead = w;
-            if ((k & 63u) == 63u || k + 2 == m) {
-                const uint32_t kb = k & ~63u;
-                if (kb + lane <= k) {
-                    S.niw[kb + lane] = pwin;
-                    S.cl[kb + lane] = (uint16_t)cwin;
-                }
-                if ((ii >> 6) == (k >> 6)) nwin = pwin;  // the node queue is still inside this window
-                pwin = INF;
+            key = zgpu_sort::merge_from<64, 32>(key);
+            const uint32_t w = key >> 7;
+            const uint32_t t = rl(w, 0) + rl(w, 1);  // at least two items are left while k + 1 < m
+            const bool real = key != INF, is_node = (key & 64u) != 0;
+            uint32_t c = (uint32_t)__builtin_popcountll(__ballot(real && w <= t));
+            if (li + 32 < m) {
+                const uint32_t cut = 64 - (uint32_t)__builtin_clzll(__ballot(real && !is_node) | 1ull);
+                c = c < cut ? c : cut;
             }
-        }
-    }
-    // ---- parents: step k consumed leaves [cl[k-1], cl[k]) and nodes [2k - cl[k-1], 2k + 2 - cl[k])
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const uint32_t k = (uint32_t)c * 64 + lane;
-        if (k + 1 < m) {
-            const uint32_t c0 = k ? S.cl[k - 1] : 0u, c1 = S.cl[k];
-            for (uint32_t i = c0; i < c1; ++i) S.parL[i] = (uint16_t)k;
-            for (uint32_t j = 2 * k - c0; j < 2 * k + 2 - c1; ++j) S.parN[j] = (uint16_t)k;
-            S.dep[k] = 1;
+            if (ii + 32 < k) {
+                const uint32_t cut = 64 - (uint32_t)__builtin_clzll(__ballot(real && is_node) | 1ull);
+                c = c < cut ? c : cut;
+            }
+            c &= ~1u;
+            const bool in = lane < c;
+            const uint32_t partner = __shfl_xor(w, 1, 64);
+            const uint32_t q = k + (lane >> 1);
+            if (in) {
+                if (!(lane & 1u)) {
+                    S.niw[q] = w + partner;
+                    S.dep[q] = 1;
+                }
+                if (is_node)
+                    S.parN[ii + (key & 31u)] = (uint16_t)q;
+                else
+                    S.parL[li + (key & 31u)] = (uint16_t)q;
+            }
+            const uint32_t nn = (uint32_t)__builtin_popcountll(__ballot(in && is_node));
+            li += c - nn;
+            ii += nn;
+            k += c >> 1;
+            asm volatile("" ::: "memory");  // the next round reads the nodes written here
         }
     }
     if (lane == 0) {

@@ -921,6 +921,12 @@ int zgpu_init(const int *device_ids, int n_devices) {
     return ZGPU_OK;
 }
 
+int zgpu_device_count(void) {
+    int count = 0;
+    HIPCHK(hipGetDeviceCount(&count));
+    return count;
+}
+
 void zgpu_shutdown(void) {
     if (g_live.load() > 0) return;  // plans or jobs still hold device state: destroy them first
     std::lock_guard<std::mutex> lk(g_mu);

@@ -41,6 +41,9 @@ struct Lib {
     fn_set2 set_search = nullptr;
     fn_set1 set_min_lazy = nullptr;
     fn_set2 set_long_match = nullptr;
+    int (*init)(const int *, int) = nullptr;
+    int (*device_count)() = nullptr;
+    int (*host_devices)(int *, int) = nullptr;
     int (*set_split)(uint64_t) = nullptr;
 } g;
 
@@ -65,15 +68,53 @@ bool need_lib(napi_env env) {
     return false;
 }
 
-// init(pathToLibzgpu)
+// Names the devices the batch calls may share: "all", or a list "0,2,3".  Touches the HIP runtime.
+napi_value name_devices(napi_env env, const std::string &spec) {
+    std::vector<int> ids;
+    if (spec == "all") {
+        const int n = g.device_count();
+        if (n < 0) return throw_zgpu(env, "zgpu_device_count", n);
+        for (int i = 0; i < n; ++i) ids.push_back(i);
+    } else {
+        size_t p = 0;
+        while (p < spec.size()) {
+            size_t q = spec.find(',', p);
+            if (q == std::string::npos) q = spec.size();
+            const std::string tok = spec.substr(p, q - p);
+            if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos) {
+                napi_throw_type_error(env, nullptr, "devices: \"all\" or a comma-separated list of device numbers");
+                return nullptr;
+            }
+            ids.push_back(std::stoi(tok));
+            p = q + 1;
+        }
+    }
+    const int rc = g.init(ids.data(), (int)ids.size());
+    if (rc != 0) return throw_zgpu(env, "zgpu_init", rc);
+    return nullptr;
+}
+
+// init(pathToLibzgpu[, devices]): loads the library; devices ("all" or "0,1,...") names the GPUs a batch is
+// split over (zgpu_init).  Without it the calls run on the current device and nothing touches the GPU here.
 napi_value Init_(napi_env env, napi_callback_info info) {
-    size_t argc = 1;
-    napi_value argv[1];
+    size_t argc = 2;
+    napi_value argv[2];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     char path[4096];
     size_t len = 0;
     NAPI_OK(napi_get_value_string_utf8(env, argv[0], path, sizeof path, &len));
-    if (g.h) return nullptr;
+    std::string devices;
+    if (argc >= 2) {
+        napi_valuetype vt;
+        NAPI_OK(napi_typeof(env, argv[1], &vt));
+        if (vt == napi_string) {
+            char buf[256];
+            size_t dl = 0;
+            NAPI_OK(napi_get_value_string_utf8(env, argv[1], buf, sizeof buf, &dl));
+            devices.assign(buf, dl);
+        }
+    }
+    if (g.h) return devices.empty() ? nullptr : name_devices(env, devices);
     void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
     if (!h) {
         napi_throw_error(env, nullptr, (std::string("cannot load ") + path + ": " + dlerror()).c_str());
@@ -92,14 +133,33 @@ napi_value Init_(napi_env env, napi_callback_info info) {
     g.set_min_lazy = (fn_set1)dlsym(h, "zgpu_set_min_lazy");
     g.set_long_match = (fn_set2)dlsym(h, "zgpu_set_long_match");
     g.set_split = (int (*)(uint64_t))dlsym(h, "zgpu_set_split");
+    g.init = (int (*)(const int *, int))dlsym(h, "zgpu_init");
+    g.device_count = (int (*)())dlsym(h, "zgpu_device_count");
+    g.host_devices = (int (*)(int *, int))dlsym(h, "zgpu_host_devices");
     if (!g.deflate_batch || !g.batch_begin || !g.batch_finish || !g.job_release || !g.checksum || !g.bound || !g.crc_combine || !g.adler_combine || !g.strerror_ ||
-        !g.set_search || !g.set_min_lazy || !g.set_split || !g.set_long_match) {
+        !g.set_search || !g.set_min_lazy || !g.set_split || !g.set_long_match || !g.init || !g.device_count || !g.host_devices) {
         dlclose(h);
         napi_throw_error(env, nullptr, "libzgpu.so lacks an expected symbol");
         return nullptr;
     }
     g.h = h;
-    return nullptr;
+    return devices.empty() ? nullptr : name_devices(env, devices);
+}
+
+// hostDevices() -> the device numbers a large batch would be split over
+napi_value HostDevices(napi_env env, napi_callback_info) {
+    if (!need_lib(env)) return nullptr;
+    int ids[64];
+    const int n = g.host_devices(ids, 64);
+    if (n < 0) return throw_zgpu(env, "zgpu_host_devices", n);
+    napi_value arr;
+    NAPI_OK(napi_create_array_with_length(env, (size_t)n, &arr));
+    for (int i = 0; i < n && i < 64; ++i) {
+        napi_value v;
+        NAPI_OK(napi_create_int32(env, ids[i], &v));
+        NAPI_OK(napi_set_element(env, arr, (uint32_t)i, v));
+    }
+    return arr;
 }
 
 bool get_u8(napi_env env, napi_value v, const uint8_t **data, size_t *len) {
@@ -331,6 +391,7 @@ napi_value SetSplit(napi_env env, napi_callback_info info) {
 napi_value ModuleInit(napi_env env, napi_value exports) {
     const napi_property_descriptor props[] = {
         {"init", nullptr, Init_, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"hostDevices", nullptr, HostDevices, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"deflateBatch", nullptr, DeflateBatch, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"checksum", nullptr, Checksum, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"crc32Combine", nullptr, Crc32Combine, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

@@ -13,7 +13,10 @@
 // lazy > 0 never emits the overlapping tail tokens of :329.
 const path = require('path');
 const addon = require('./zgpu_addon.node');
-addon.init(path.join(__dirname, '..', 'libzgpu.so'));
+// ZGPU_DEVICES ("all", or "0,1,...") names the GPUs a large batch (Zip.compress(), the chunked helpers,
+// compressBatch) is split over inside the library; unset, the calls run on the current device.
+if (process.env.ZGPU_DEVICES) addon.init(process.env.ZGPU_LIB || path.join(__dirname, '..', 'libzgpu.so'), process.env.ZGPU_DEVICES);
+else addon.init(process.env.ZGPU_LIB || path.join(__dirname, '..', 'libzgpu.so'));
 
 const F_FINAL_EACH = 1, F_SYNC_ALIGN = 2, F_FINAL_LAST = 4, F_PRIME_WINDOW = 8;
 
