@@ -36,7 +36,7 @@ enum {
     ZGPU_E_ARG = -2,      /* bad argument ("invalid compression type", rawdeflate.js:121) */
     ZGPU_E_NOMEM = -3,    /* device or host allocation failed */
     ZGPU_E_OUTCAP = -4,   /* output capacity too small */
-    ZGPU_E_UNIT = -5,     /* a unit overflowed its bounded output slot */
+    ZGPU_E_UNIT = -5,     /* a unit's emitted size differs from its computed size, or it overflowed its bound (internal error) */
     ZGPU_E_TOOBIG = -6    /* a unit exceeds ZGPU_MAX_UNIT_BYTES */
 };
 
@@ -193,8 +193,13 @@ void zgpu_plan_destroy(zgpu_plan *plan);
 /* bytes d_out must hold for zgpu_plan_run (sum of per-unit bounds) */
 uint64_t zgpu_plan_out_bound(const zgpu_plan *plan);
 /* d_in: device pointer to in_off[n_units] input bytes; d_out: device buffer
- * of out_cap bytes.  stream: hipStream_t (NULL = default stream).  Returns
- * after enqueueing. */
+ * of out_cap bytes, 4-byte aligned (ZGPU_E_ARG otherwise).  The compressed
+ * units land back to back from d_out on; units that do not fit out_cap are
+ * left out and reported by zgpu_plan_fetch.  Plans of units longer than 16 KiB
+ * write every unit straight to its final place (sizes first, then offsets by
+ * a look-back among the units in flight); plans with a round of smaller units
+ * stage them in a workspace and gather.  stream: hipStream_t (NULL = default
+ * stream).  Returns after enqueueing. */
 int zgpu_plan_run(zgpu_plan *plan, const void *d_in, void *d_out, uint64_t out_cap, void *stream);
 /* Device-side results of the last run (valid once the stream has drained):
  * out_off: n_units+1 x uint64, crc/adler: n_units x uint32 (zero unless
@@ -204,7 +209,8 @@ const uint32_t *zgpu_plan_crc_device(const zgpu_plan *plan);
 const uint32_t *zgpu_plan_adler_device(const zgpu_plan *plan);
 /* Waits for the stream, copies results to host arrays (any may be NULL) and
  * returns ZGPU_E_OUTCAP if d_out was too small for the compressed bytes, else
- * ZGPU_E_UNIT if a unit overflowed its bounded slot. */
+ * ZGPU_E_UNIT if a unit's emitted size disagreed with its computed size or
+ * its bound (an internal error; never seen in the tests). */
 int zgpu_plan_fetch(zgpu_plan *plan, uint64_t *out_off, uint32_t *crc32, uint32_t *adler32,
                     void *stream);
 /* Device time of the last run in milliseconds, measured with HIP events on the

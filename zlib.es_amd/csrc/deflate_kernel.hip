@@ -1414,20 +1414,36 @@ namespace {
 // words, coalesced dword stores.  Blocks of a unit follow each other at bit
 // granularity, so a unit's blocks are emitted in order by one workgroup; many
 // workgroups share a CU and hide each other's serial stretches.
+// HCLEN order of the code-length symbols (RFC 1951 3.2.7): 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15
+__device__ inline uint32_t hclen_order(uint32_t i) {
+    const uint64_t oa = 0x0609070800121110ull;  // order[0..7], one byte each
+    const uint64_t ob = 0x020d030c040b050aull;  // order[8..15]
+    const uint32_t oc = 0x000f010eu;            // order[16..18]
+    return i < 8 ? (uint32_t)(oa >> (8 * i)) & 0xffu : i < 16 ? (uint32_t)(ob >> (8 * (i - 8))) & 0xffu : i < 19 ? (oc >> (8 * (i - 16))) & 0xffu : 0u;
+}
+
+#ifndef ZGPU_EMIT_WAVES
+#define ZGPU_EMIT_WAVES 8
+#endif
 struct EParams {
     const uint64_t *in_off;    // n_units+1 (unit sizes)
-    const uint64_t *slot_off;  // n_units+1, 16-byte aligned output slots in out_tmp
-    uint8_t *out_tmp;
+    uint8_t *out;              // direct: the caller's output buffer (4-byte aligned), units land at their final
+                               // offsets; slots: a staging buffer, unit u goes to its bounded slot
+    uint64_t out_cap;
+    const uint64_t *slot_off;  // slots: n_units+1, 16-byte aligned
+    uint64_t *out_off;         // n_total+1: exclusive prefix of the unit sizes, written here
+    unsigned long long *state; // n_total look-back words, zero before the first round: flag << 62 | bytes
     uint32_t *out_size;        // n_units
-    uint32_t *status;          // n_units
+    uint32_t *status;          // n_units: 0 ok, 1 emitted size differs from the computed one / slot too small, 2 out_cap too small
     const uint16_t *tok;       // token slots of this round
     const uint64_t *tok_off;   // n_units: first token of the unit within tok
     const uint32_t *blk_first; // n_units: index of the unit's first block
-    const uint32_t *hist;      // blocks x 320 symbol counts (lit/len 288, dist 32)
+    uint32_t *hist;            // blocks x 320 symbol counts (lit/len 288, dist 32); a multi-block unit's code
+                               // tables are parked here between its sizing and its emission
     const uint32_t *ntok;      // blocks: tokens incl. end-of-block
     uint32_t *counter;         // unit queue head (relative to unit_first)
     const uint8_t *unit_final; // n_units: 1 = the unit ends its stream (BFINAL), 0 = it ends with an empty stored block
-    uint32_t unit_first, unit_end;
+    uint32_t unit_first, unit_end, n_total;
     int ctype;
     unsigned long long *prof;  // diagnostic builds: 16 per-phase cycle sums of each unit's thread 0
 };
@@ -1442,69 +1458,267 @@ __device__ __forceinline__ void group_sync() {
         __syncthreads();
 }
 
+// Look-back over the units before u (decoupled: every unit first publishes its own size, then adds up
+// its predecessors' until it meets one that already knows its inclusive prefix).  Called by one whole
+// wave; returns the sum of the sizes of units [0, u).  A unit publishes before it waits and waits only
+// for units whose tickets were drawn earlier, i.e. by workgroups that are running: no deadlock.  The wait
+// is bounded all the same (a fraction of a second): ~0 comes back if a predecessor never showed up.
+__device__ inline uint64_t lookback_offset(unsigned long long *state, uint32_t u, uint32_t bytes) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long VMASK = (1ull << 62) - 1ull;
+    if (lane == 0)
+        __hip_atomic_store(&state[u], ((u ? 1ull : 2ull) << 62) | bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t excl = 0;
+    long long idx = (long long)u - 1;  // nearest unit not yet accounted for
+    uint32_t spins = 0;
+    while (idx >= 0) {
+        const long long my = idx - lane;
+        unsigned long long v = 2ull << 62;  // before unit 0: an inclusive prefix of zero
+        if (my >= 0) v = __hip_atomic_load(&state[my], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t flag = (uint32_t)(v >> 62);
+        const unsigned long long incl = __ballot(flag == 2), none = __ballot(flag == 0);
+        const bool have = incl != 0;
+        const int fi = have ? __builtin_ctzll(incl) : 63;  // nearest unit that knows its inclusive prefix
+        const unsigned long long need = fi < 63 ? (1ull << (fi + 1)) - 1ull : ~0ull;  // lanes up to that unit
+        if (none & need) {  // a unit on the way has not published yet
+            if (++spins > (1u << 22)) return ~0ull;
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        unsigned long long c = ((need >> lane) & 1ull) ? (v & VMASK) : 0ull;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+        excl += c;
+        if (have) break;
+        idx -= 64;
+    }
+    if (lane == 0 && u)
+        __hip_atomic_store(&state[u], (2ull << 62) | (excl + bytes), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
 // NT threads per unit: 256 (a workgroup; units of any size) or 64 (one wave per unit, four units
 // side by side in a workgroup: for small units the serial stretches of the code construction are
-// what takes the time, and more of them then run at once)
-template <int NT>
+// what takes the time, and more of them then run at once).
+//
+// DIRECT: a unit is written straight to its final place in the caller's buffer: (1) the code tables
+// and the header fields of its block(s) are built and the exact size follows from the histograms,
+// (2) the look-back turns sizes into offsets, (3) header and tokens are emitted there.  A unit's
+// first and last bytes may share a 32-bit word with its neighbours: those are stored bytewise.
+// Otherwise (plans with rounds of small units: thousands of them are in flight at once and the
+// look-back, a global round trip or several per unit, costs more than a gathering pass over the small
+// output) a unit goes to its bounded slot of a staging buffer, block by block without the sizing
+// step, and zgpu_scan_kernel / zgpu_compact_kernel place the units afterwards.
+template <int NT, bool DIRECT>
 __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
     constexpr int EWG = NT;                  // shadows the workgroup-wide constants above
     constexpr int ETOK = 4 * NT;
     constexpr int STAGE_WORDS = stage_words(NT);
     constexpr uint32_t E_HUF = E_STAGE + (uint32_t)STAGE_WORDS * 4;
+    constexpr int M_META = 56;  // hlit, hdist, hclen, run-length items, header bits
+    constexpr int M_EXCL = 38;  // [2] the unit's byte offset
     const int tid = threadIdx.x % NT, lane = tid & 63, wave = tid >> 6;
     uint32_t *fl = (uint32_t *)(lds + E_FL), *fd = fl + 288, *misc = (uint32_t *)(lds + E_MISC);
     uint32_t *lltab = (uint32_t *)(lds + E_LLTAB), *dtab = (uint32_t *)(lds + E_DTAB);
     uint32_t *stage = (uint32_t *)(lds + E_STAGE);
+    uint16_t *rle = (uint16_t *)(lds + E_HUF + H_RLE);
+    uint32_t *clf = (uint32_t *)(lds + E_HUF + H_CLF);
+    uint32_t *cltab = (uint32_t *)(lds + E_HUF + H_CLTAB);
+    const uint32_t INF = 0xffffffffu;
     PH_DECL;
     PH_START();
-    for (;;) {
-        if (tid == 0) misc[M_UNIT] = P.unit_first + atomicAdd(P.counter, 1u);
-        group_sync<NT>();
-        const uint32_t u = misc[M_UNIT];
-        group_sync<NT>();
-        if (u >= P.unit_end) break;
-        PH_END(0);
-        const uint32_t n = (uint32_t)(P.in_off[u + 1] - P.in_off[u]);
-        uint32_t *out32 = (uint32_t *)(P.out_tmp + P.slot_off[u]);
-        const uint32_t cap_words = (uint32_t)((P.slot_off[u + 1] - P.slot_off[u]) >> 2);
-        const bool final_unit = P.unit_final[u] != 0;
-        const uint32_t nblk = n ? (n + ZGPU_BLOCK_BYTES - 1) / ZGPU_BLOCK_BYTES : 1u;
-        uint32_t bitpos = 0;     // bits emitted so far in this unit (uniform)
-        uint32_t base_word = 0;  // output word index of stage[0] (uniform)
-        if (tid == 0) misc[M_OVF] = 0;
-        for (int i = tid; i < STAGE_WORDS; i += EWG) stage[i] = 0;
-        for (uint32_t blk = 0; blk < nblk; ++blk) {
-            const uint32_t gb = P.blk_first[u] + blk;
-            const uint16_t *tokbuf = P.tok + P.tok_off[u] + (uint64_t)blk * ZGPU_BLOCK_TOK;
-            const uint32_t ntok = P.ntok[gb];
-            const uint32_t bfinal = (blk + 1 == nblk && final_unit) ? 1u : 0u;
-            for (int i = tid; i < 320; i += EWG) fl[i] = P.hist[(size_t)gb * 320 + i];
-            group_sync<NT>();
-            PH_END(1);
-            // stage[] holds the unit's partial last word at [0] and is zero elsewhere
-            BitW bw{stage, bitpos - base_word * 32};
-            if (P.ctype == 2) {
-                const HufS TL = huf_scratch(lds + E_HUF + H_TL, 288), TD = huf_scratch(lds + E_HUF + H_TD, 32);
-                const uint32_t INF = 0xffffffffu;
-                // every code set gets at least two symbols, so it is complete: a block that
-                // holds only the end-of-block symbol gains literal 0, and the distance
-                // alphabet is topped up to two used symbols
-                if (tid == 0 && ntok < 2) fl[0] = 1;
-                if (wave == (NT == 64 ? 0 : 1)) {
-                    const unsigned long long nz = __ballot(lane < 30 && fd[lane] != 0);
-                    const int c = __builtin_popcountll(nz);
-                    if (c < 2 && lane == 0) {
-                        if (c == 0) fd[0] = 1;
-                        fd[(c == 0 || (nz & 1ull)) ? 1 : 0] = 1;
-                    }
+
+    // ---- header fields from the code lengths in lltab / dtab (one whole wave): HLIT/HDIST, run-length
+    // items, code-length code, and the header's size in bits
+    auto header_fields = [&]() {
+        const HufS TD = huf_scratch(lds + E_HUF + H_TD, 32);
+        const uint32_t ulane = (uint32_t)lane;
+        if (lane < 32) clf[lane] = 0;
+        // HLIT / HDIST: trailing unused symbols are not sent (at least 257 / 1)
+        uint32_t hlit, hdist;
+        {
+            const unsigned long long mh = __ballot(256 + lane < 286 && (lltab[256 + lane] >> 16) != 0);
+            hlit = 256 + 64 - (uint32_t)__builtin_clzll(mh | 1ull);  // symbol 256 is always used
+            if (hlit < 257) hlit = 257;
+            const unsigned long long md = __ballot(lane < 30 && (dtab[lane & 31] >> 16) != 0);
+            hdist = 64 - (uint32_t)__builtin_clzll(md | 1ull);
+        }
+        const uint32_t tot = hlit + hdist;
+        // code lengths of the concatenated alphabets, 64 per chunk; run starts
+        uint32_t Lv[5];
+        unsigned long long St[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const uint32_t i = (uint32_t)c * 64 + ulane;
+            Lv[c] = i < hlit ? lltab[i] >> 16 : (i < tot ? dtab[(i - hlit) & 31] >> 16 : 0xffu);
+        }
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const uint32_t i = (uint32_t)c * 64 + ulane;
+            const uint32_t pl = c ? rl(Lv[c ? c - 1 : 0], 63) : 0xffffu;  // last of the previous chunk
+            uint32_t pv = __shfl_up(Lv[c], 1, 64);
+            if (lane == 0) pv = pl;
+            St[c] = __ballot(i <= tot && (i == tot || Lv[c] != pv));  // index tot closes the last run
+        }
+        // items per run (greedy: 18 for 11..138 zeros, 17 for 3..10, 16 for 3..6 repeats)
+        uint32_t run[5], cnt[5], off[5];
+        uint32_t nr = 0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const uint32_t i = (uint32_t)c * 64 + ulane;
+            const bool start = i < tot && ((St[c] >> ulane) & 1ull);
+            uint32_t nxt = tot;
+            {
+                const unsigned long long above = lane == 63 ? 0ull : (St[c] >> (ulane + 1)) << (ulane + 1);
+                bool found = false;
+                if (above) {
+                    nxt = (uint32_t)c * 64 + (uint32_t)__builtin_ctzll(above);
+                    found = true;
                 }
-                group_sync<NT>();
-                // ---- sort keys (weight << 9 | symbol, unused = INF) ----
-                for (int i = tid; i < 288; i += EWG)
-                    TL.niw[i] = (i < 286 && fl[i]) ? ((fl[i] << 9) | (uint32_t)i) : INF;
-                if (tid < 32) TD.niw[tid] = (tid < 30 && fd[tid]) ? ((fd[tid] << 9) | (uint32_t)tid) : INF;
-                group_sync<NT>();
-                if constexpr (NT == 256) {
+#pragma unroll
+                for (int c2 = c + 1; c2 < 5; ++c2)
+                    if (!found && St[c2]) {
+                        nxt = (uint32_t)c2 * 64 + (uint32_t)__builtin_ctzll(St[c2]);
+                        found = true;
+                    }
+            }
+            uint32_t r = start ? nxt - i : 0u, n = 0;
+            if (start) {
+                if (Lv[c] == 0) {
+                    const uint32_t q = r / 138u, rem = r % 138u;
+                    n = q + (rem >= 3 ? 1u : rem);
+                } else {
+                    const uint32_t q = (r - 1) / 6u, rem = (r - 1) % 6u;
+                    n = 1 + q + (rem >= 3 ? 1u : rem);
+                }
+            }
+            run[c] = r;
+            cnt[c] = n;
+            uint32_t inc = n;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += y;
+            }
+            off[c] = nr + inc - n;
+            nr += rl(inc, 63);
+        }
+        // write the items, count the code-length symbols
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            if (cnt[c]) {
+                uint32_t r = run[c], o = off[c];
+                const uint32_t v = Lv[c];
+                if (v == 0) {
+                    uint32_t n18 = 0, n17 = 0, n0 = 0;
+                    while (r >= 11) {
+                        const uint32_t t = r > 138 ? 138 : r;
+                        rle[o++] = (uint16_t)(18 | ((t - 11) << 8));
+                        ++n18;
+                        r -= t;
+                    }
+                    if (r >= 3) {
+                        rle[o++] = (uint16_t)(17 | ((r - 3) << 8));
+                        ++n17;
+                        r = 0;
+                    }
+                    while (r--) {
+                        rle[o++] = 0;
+                        ++n0;
+                    }
+                    if (n18) atomicAdd(&clf[18], n18);
+                    if (n17) atomicAdd(&clf[17], n17);
+                    if (n0) atomicAdd(&clf[0], n0);
+                } else {
+                    uint32_t nv = 1, n16 = 0;
+                    rle[o++] = (uint16_t)v;
+                    --r;
+                    while (r >= 3) {
+                        const uint32_t t = r > 6 ? 6 : r;
+                        rle[o++] = (uint16_t)(16 | ((t - 3) << 8));
+                        ++n16;
+                        r -= t;
+                    }
+                    while (r--) {
+                        rle[o++] = (uint16_t)v;
+                        ++nv;
+                    }
+                    atomicAdd(&clf[v], nv);
+                    if (n16) atomicAdd(&clf[16], n16);
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        PH_END(5);
+        // ---- code-length code (19 symbols, 7 bits) ----
+        {
+            uint32_t f = lane < 19 ? clf[lane] : 0u;
+            const unsigned long long nz = __ballot(f != 0);
+            if (__builtin_popcountll(nz) < 2 && ulane == ((nz & 1ull) ? 1u : 0u)) f = 1;
+            uint32_t key = f ? ((f << 9) | ulane) : INF;
+            key = wave_sort64(key);
+            const uint32_t mC = (uint32_t)__builtin_popcountll(__ballot(key != INF));
+            if (lane < 32) TD.sorted[lane] = key;
+            asm volatile("" ::: "memory");
+            wave_huffman<1>(TD, mC, 19, 7, cltab);
+        }
+        asm volatile("" ::: "memory");
+        PH_END(6);
+        // ---- size of the header: 17 bits, 3 per sent code-length length, the items
+        uint32_t hclen;
+        {
+            const uint32_t cll = lane < 19 ? cltab[hclen_order(ulane)] >> 16 : 0u;
+            const unsigned long long mu = __ballot(cll != 0);
+            hclen = 64 - (uint32_t)__builtin_clzll(mu | 1ull);
+            if (hclen < 4) hclen = 4;
+        }
+        uint32_t hbits = 0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const uint32_t t = (uint32_t)c * 64 + ulane;
+            if (t < nr) {
+                const uint32_t sym = rle[t] & 0xffu;
+                hbits += (cltab[sym] >> 16) + (sym == 16 ? 2u : sym == 17 ? 3u : sym == 18 ? 7u : 0u);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) hbits += __shfl_xor(hbits, d, 64);
+        if (lane == 0) {
+            misc[M_META] = hlit;
+            misc[M_META + 1] = hdist;
+            misc[M_META + 2] = hclen;
+            misc[M_META + 3] = nr;
+            misc[M_META + 4] = 17 + 3 * hclen + hbits;
+        }
+    };
+
+    // ---- code tables of block gb into lltab / dtab, header fields into rle / cltab / misc[M_META..];
+    // returns the block's size in bits (header + tokens)
+    auto build_block = [&](uint32_t gb, uint32_t ntok) -> uint32_t {
+        for (int i = tid; i < 320; i += EWG) fl[i] = P.hist[(size_t)gb * 320 + i];
+        group_sync<NT>();
+        PH_END(1);
+        if (P.ctype == 2) {
+            const HufS TL = huf_scratch(lds + E_HUF + H_TL, 288), TD = huf_scratch(lds + E_HUF + H_TD, 32);
+            // every code set gets at least two symbols, so it is complete: a block that
+            // holds only the end-of-block symbol gains literal 0, and the distance
+            // alphabet is topped up to two used symbols
+            if (tid == 0 && ntok < 2) fl[0] = 1;
+            if (wave == (NT == 64 ? 0 : 1)) {
+                const unsigned long long nz = __ballot(lane < 30 && fd[lane] != 0);
+                const int c = __builtin_popcountll(nz);
+                if (c < 2 && lane == 0) {
+                    if (c == 0) fd[0] = 1;
+                    fd[(c == 0 || (nz & 1ull)) ? 1 : 0] = 1;
+                }
+            }
+            group_sync<NT>();
+            // ---- sort keys (weight << 9 | symbol, unused = INF) ----
+            for (int i = tid; i < 288; i += EWG)
+                TL.niw[i] = (i < 286 && fl[i]) ? ((fl[i] << 9) | (uint32_t)i) : INF;
+            if (tid < 32) TD.niw[tid] = (tid < 30 && fd[tid]) ? ((fd[tid] << 9) | (uint32_t)tid) : INF;
+            group_sync<NT>();
+            if constexpr (NT == 256) {
                 // ---- rank sort: a key's rank is the number of smaller keys ----
                 uint32_t rk0 = 0, rk1 = 0, key0, key1 = INF;
                 {
@@ -1532,226 +1746,208 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
                 if (tid == 95) misc[M_TMP] = rk1;   // dist key 31
                 if (key0 != INF) TL.sorted[rk0] = key0;
                 if (key1 != INF) (tid < 32 ? TL.sorted : TD.sorted)[rk1] = key1;
-                } else {
-                    // one wave: the used symbols are packed first (a small unit uses few), then sorted
-                    // in registers when they fit a wave, else ranked against each other
-                    const unsigned long long lt = (1ull << lane) - 1ull;
-                    uint32_t *U = TL.rank;  // free until the tree is built
-                    uint32_t m = 0;
+            } else {
+                // one wave: the used symbols are packed first (a small unit uses few), then sorted
+                // in registers when they fit a wave, else ranked against each other
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                uint32_t *U = TL.rank;  // free until the tree is built
+                uint32_t m = 0;
 #pragma unroll
-                    for (int c = 0; c < 5; ++c) {
-                        const uint32_t i = (uint32_t)c * 64 + (uint32_t)lane;
-                        const uint32_t key = i < 288 ? TL.niw[i] : INF;
-                        const unsigned long long mk = __ballot(key != INF);
-                        if (key != INF) U[m + (uint32_t)__builtin_popcountll(mk & lt)] = key;
-                        m += (uint32_t)__builtin_popcountll(mk);
-                    }
-                    group_sync<NT>();
-                    if (m <= 64) {
-                        uint32_t key = (uint32_t)lane < m ? U[lane] : INF;
-                        key = wave_sort64(key);
-                        if ((uint32_t)lane < m) TL.sorted[lane] = key;
-                    } else {
-                        const uint32_t m4 = (m + 3) & ~3u;
-                        if ((uint32_t)lane < m4 - m) U[m + lane] = INF;  // pad to whole uint4 reads
-                        group_sync<NT>();
-                        const uint4 *kp = (const uint4 *)U;
-                        for (uint32_t i = (uint32_t)lane; i < m; i += 64) {
-                            const uint32_t key = U[i];
-                            uint32_t rk = 0;
-                            for (uint32_t j = 0; j < m4 / 4; ++j) {
-                                const uint4 q = kp[j];
-                                rk += (q.x < key) + (q.y < key) + (q.z < key) + (q.w < key);
-                            }
-                            TL.sorted[rk] = key;
-                        }
-                    }
-                    uint32_t dk = lane < 32 ? TD.niw[lane] : INF;
-                    dk = wave_sort64(dk);
-                    if (lane < 32) TD.sorted[lane] = dk;
-                    const uint32_t md = (uint32_t)__builtin_popcountll(__ballot(dk != INF));  // all lanes vote
-                    if (lane == 0) {
-                        misc[M_NTOK] = m;
-                        misc[M_TMP] = md;
-                    }
+                for (int c = 0; c < 5; ++c) {
+                    const uint32_t i = (uint32_t)c * 64 + (uint32_t)lane;
+                    const uint32_t key = i < 288 ? TL.niw[i] : INF;
+                    const unsigned long long mk = __ballot(key != INF);
+                    if (key != INF) U[m + (uint32_t)__builtin_popcountll(mk & lt)] = key;
+                    m += (uint32_t)__builtin_popcountll(mk);
                 }
                 group_sync<NT>();
-                PH_END(2);
-                const uint32_t mL = misc[M_NTOK], mD = misc[M_TMP];
-                // ---- the two trees, one wave each ----
-                if (wave == 0) wave_huffman<5>(TL, mL, 286, 15, lltab);
-                if (NT == 64) PH_END(3);
-                if (wave == (NT == 64 ? 0 : 1)) wave_huffman<1>(TD, mD, 30, 15, dtab);
+                if (m <= 64) {
+                    uint32_t key = (uint32_t)lane < m ? U[lane] : INF;
+                    key = wave_sort64(key);
+                    if ((uint32_t)lane < m) TL.sorted[lane] = key;
+                } else {
+                    const uint32_t m4 = (m + 3) & ~3u;
+                    if ((uint32_t)lane < m4 - m) U[m + lane] = INF;  // pad to whole uint4 reads
+                    group_sync<NT>();
+                    const uint4 *kp = (const uint4 *)U;
+                    for (uint32_t i = (uint32_t)lane; i < m; i += 64) {
+                        const uint32_t key = U[i];
+                        uint32_t rk = 0;
+                        for (uint32_t j = 0; j < m4 / 4; ++j) {
+                            const uint4 q = kp[j];
+                            rk += (q.x < key) + (q.y < key) + (q.z < key) + (q.w < key);
+                        }
+                        TL.sorted[rk] = key;
+                    }
+                }
+                uint32_t dk = lane < 32 ? TD.niw[lane] : INF;
+                dk = wave_sort64(dk);
+                if (lane < 32) TD.sorted[lane] = dk;
+                const uint32_t md = (uint32_t)__builtin_popcountll(__ballot(dk != INF));  // all lanes vote
+                if (lane == 0) {
+                    misc[M_NTOK] = m;
+                    misc[M_TMP] = md;
+                }
+            }
+            group_sync<NT>();
+            PH_END(2);
+            const uint32_t mL = misc[M_NTOK], mD = misc[M_TMP];
+            // ---- the two trees, one wave each ----
+            if (wave == 0) wave_huffman<5>(TL, mL, 286, 15, lltab);
+            if (NT == 64) PH_END(3);
+            if (wave == (NT == 64 ? 0 : 1)) wave_huffman<1>(TD, mD, 30, 15, dtab);
+            group_sync<NT>();
+            PH_END(4);
+            if (wave == 0) header_fields();
+        } else {
+            // fixed Huffman codes (RFC 1951 3.2.6; FixedHuffmanTable rawdeflate.js:48-68)
+            for (int sy = tid; sy < 288; sy += EWG) {
+                uint32_t c, l;
+                if (sy <= 143) {
+                    c = 0x30 + sy;
+                    l = 8;
+                } else if (sy <= 255) {
+                    c = 0x190 + sy - 144;
+                    l = 9;
+                } else if (sy <= 279) {
+                    c = sy - 256;
+                    l = 7;
+                } else {
+                    c = 0xc0 + sy - 280;
+                    l = 8;
+                }
+                lltab[sy] = (__brev(c) >> (32 - l)) | (l << 16);
+            }
+            if (tid < 32) dtab[tid] = (__brev((uint32_t)tid) >> 27) | (5u << 16);
+            if (tid == 0) misc[M_META + 4] = 3;
+        }
+        group_sync<NT>();
+        if constexpr (!DIRECT) return 0u;
+        // ---- bits of the tokens: counts (as the search kernel left them: the top-ups above are
+        // codes without tokens) times code length plus extra bits
+        uint32_t mine = 0;
+        for (int i = tid; i < 320; i += EWG) {
+            const uint32_t n = P.hist[(size_t)gb * 320 + i];
+            if (!n) continue;
+            uint32_t bits;
+            if (i < 288) {
+                bits = lltab[i] >> 16;
+                if (i >= 265 && i < 285) bits += ((uint32_t)i - 261u) >> 2;
+            } else {
+                const uint32_t d = (uint32_t)i - 288u;
+                bits = (dtab[d] >> 16) + (d >= 4 ? (d >> 1) - 1u : 0u);
+            }
+            mine += n * bits;
+        }
+        uint32_t total;
+        (void)group_scan_excl<NT>(mine, &total, misc + M_SCAN);
+        group_sync<NT>();
+        return total + misc[M_META + 4];
+    };
+
+    for (;;) {
+        if (tid == 0) misc[M_UNIT] = P.unit_first + atomicAdd(P.counter, 1u);
+        group_sync<NT>();
+        const uint32_t u = misc[M_UNIT];
+        group_sync<NT>();
+        if (u >= P.unit_end) break;
+        PH_END(0);
+        const uint32_t n = (uint32_t)(P.in_off[u + 1] - P.in_off[u]);
+        const bool final_unit = P.unit_final[u] != 0;
+        const uint32_t nblk = n ? (n + ZGPU_BLOCK_BYTES - 1) / ZGPU_BLOCK_BYTES : 1u;
+        const uint32_t gb0 = P.blk_first[u];
+        const uint16_t *tok0 = P.tok + P.tok_off[u];
+        uint32_t unit_bytes = 0;
+        uint32_t cap_words = 0xffffffffu;  // slots: room of the unit's slot
+        if constexpr (DIRECT) {
+            // ---- (1) size of the unit ----
+            uint32_t unit_bits = 0;
+            for (uint32_t blk = 0; blk < nblk; ++blk) {
+                const uint32_t gb = gb0 + blk;
+                unit_bits += build_block(gb, P.ntok[gb]);
+                if (nblk > 1 && P.ctype == 2) {
+                    // park the code tables where the block's histogram was (320 words either way); the
+                    // header fields are rebuilt from them when the block is emitted
+                    for (int i = tid; i < 320; i += EWG) P.hist[(size_t)gb * 320 + i] = lltab[i];  // lltab, dtab adjoin
+                    group_sync<NT>();
+                }
+            }
+            // byte-align; a chunk that is followed by more of the same stream ends with an empty stored block
+            unit_bytes = final_unit ? (unit_bits + 7) >> 3 : ((unit_bits + 3 + 7) >> 3) + 4;
+            // ---- (2) its place ----
+            if (wave == 0) {
+                const uint64_t e = lookback_offset(P.state, u, unit_bytes);
+                if (lane == 0) {
+                    misc[M_EXCL] = (uint32_t)e;
+                    misc[M_EXCL + 1] = (uint32_t)(e >> 32);
+                    P.out_off[u] = e;
+                    if (u + 1 == P.n_total) P.out_off[u + 1] = e + unit_bytes;
+                    P.out_size[u] = unit_bytes;
+                }
+            }
+        } else {
+            const uint64_t so = P.slot_off[u];
+            cap_words = (uint32_t)((P.slot_off[u + 1] - so) >> 2);
+            if (tid == 0) {
+                misc[M_EXCL] = (uint32_t)so;
+                misc[M_EXCL + 1] = (uint32_t)(so >> 32);
+                misc[M_OVF] = 0;
+            }
+        }
+        for (int i = tid; i < STAGE_WORDS; i += EWG) stage[i] = 0;
+        group_sync<NT>();
+        const uint64_t excl = (uint64_t)misc[M_EXCL] | ((uint64_t)misc[M_EXCL + 1] << 32);
+        const bool placed = excl != ~0ull, fits = placed && (!DIRECT || excl + unit_bytes <= P.out_cap);
+        const uint32_t head = (uint32_t)(excl & 3u);  // bytes of the first word that belong to the unit before
+        uint32_t *out32 = (uint32_t *)(P.out + (excl - head));
+        uint32_t bitpos = 8 * head;  // bits so far, counted from the first word's start (uniform)
+        uint32_t base_word = 0;      // output word index of stage[0] (uniform)
+        // a full word goes out whole unless it is the unit's first and shared with the unit before
+        auto store_word = [&](uint32_t wi, uint32_t w) {
+            if constexpr (!DIRECT) {
+                if (wi < cap_words)
+                    out32[wi] = w;
+                else
+                    misc[M_OVF] = 1;
+            } else if (wi == 0 && head) {
+                uint8_t *b = (uint8_t *)out32;
+                for (uint32_t k = head; k < 4; ++k) b[k] = (uint8_t)(w >> (8 * k));
+            } else
+                out32[wi] = w;
+        };
+        // ---- (3) header and tokens, block by block ----
+        for (uint32_t blk = 0; blk < nblk; ++blk) {
+            const uint32_t gb = gb0 + blk;
+            const uint16_t *tokbuf = tok0 + (uint64_t)blk * ZGPU_BLOCK_TOK;
+            const uint32_t ntok = P.ntok[gb];
+            const uint32_t bfinal = (blk + 1 == nblk && final_unit) ? 1u : 0u;
+            if constexpr (!DIRECT) {
+                (void)build_block(gb, ntok);
+            } else if (nblk > 1 && P.ctype == 2) {
+                // the tables parked at sizing time come back; the header fields are rebuilt from them
+                for (int i = tid; i < 320; i += EWG) lltab[i] = P.hist[(size_t)gb * 320 + i];
                 group_sync<NT>();
-                PH_END(4);
-                // ---- header (wave 0): HLIT/HDIST, run-length items, code-length code, bits ----
-                if (wave == 0) {
-                    uint16_t *rle = (uint16_t *)(lds + E_HUF + H_RLE);
-                    uint32_t *clf = (uint32_t *)(lds + E_HUF + H_CLF);
-                    uint32_t *cltab = (uint32_t *)(lds + E_HUF + H_CLTAB);
-                    const uint32_t ulane = (uint32_t)lane;
-                    if (lane < 32) clf[lane] = 0;
-                    // HLIT / HDIST: trailing unused symbols are not sent (at least 257 / 1)
-                    uint32_t hlit, hdist;
-                    {
-                        const unsigned long long mh = __ballot(256 + lane < 286 && (lltab[256 + lane] >> 16) != 0);
-                        hlit = 256 + 64 - (uint32_t)__builtin_clzll(mh | 1ull);  // symbol 256 is always used
-                        if (hlit < 257) hlit = 257;
-                        const unsigned long long md = __ballot(lane < 30 && (dtab[lane & 31] >> 16) != 0);
-                        hdist = 64 - (uint32_t)__builtin_clzll(md | 1ull);
-                    }
-                    const uint32_t tot = hlit + hdist;
-                    // code lengths of the concatenated alphabets, 64 per chunk; run starts
-                    uint32_t Lv[5];
-                    unsigned long long St[5];
-#pragma unroll
-                    for (int c = 0; c < 5; ++c) {
-                        const uint32_t i = (uint32_t)c * 64 + ulane;
-                        Lv[c] = i < hlit ? lltab[i] >> 16 : (i < tot ? dtab[(i - hlit) & 31] >> 16 : 0xffu);
-                    }
-#pragma unroll
-                    for (int c = 0; c < 5; ++c) {
-                        const uint32_t i = (uint32_t)c * 64 + ulane;
-                        const uint32_t pl = c ? rl(Lv[c ? c - 1 : 0], 63) : 0xffffu;  // last of the previous chunk
-                        uint32_t pv = __shfl_up(Lv[c], 1, 64);
-                        if (lane == 0) pv = pl;
-                        St[c] = __ballot(i <= tot && (i == tot || Lv[c] != pv));  // index tot closes the last run
-                    }
-                    // items per run (greedy: 18 for 11..138 zeros, 17 for 3..10, 16 for 3..6 repeats)
-                    uint32_t run[5], cnt[5], off[5];
-                    uint32_t nr = 0;
-#pragma unroll
-                    for (int c = 0; c < 5; ++c) {
-                        const uint32_t i = (uint32_t)c * 64 + ulane;
-                        const bool start = i < tot && ((St[c] >> ulane) & 1ull);
-                        uint32_t nxt = tot;
-                        {
-                            const unsigned long long above = lane == 63 ? 0ull : (St[c] >> (ulane + 1)) << (ulane + 1);
-                            bool found = false;
-                            if (above) {
-                                nxt = (uint32_t)c * 64 + (uint32_t)__builtin_ctzll(above);
-                                found = true;
-                            }
-#pragma unroll
-                            for (int c2 = c + 1; c2 < 5; ++c2)
-                                if (!found && St[c2]) {
-                                    nxt = (uint32_t)c2 * 64 + (uint32_t)__builtin_ctzll(St[c2]);
-                                    found = true;
-                                }
-                        }
-                        uint32_t r = start ? nxt - i : 0u, n = 0;
-                        if (start) {
-                            if (Lv[c] == 0) {
-                                const uint32_t q = r / 138u, rem = r % 138u;
-                                n = q + (rem >= 3 ? 1u : rem);
-                            } else {
-                                const uint32_t q = (r - 1) / 6u, rem = (r - 1) % 6u;
-                                n = 1 + q + (rem >= 3 ? 1u : rem);
-                            }
-                        }
-                        run[c] = r;
-                        cnt[c] = n;
-                        uint32_t inc = n;
-#pragma unroll
-                        for (int d = 1; d < 64; d <<= 1) {
-                            const uint32_t y = __shfl_up(inc, d, 64);
-                            if (lane >= d) inc += y;
-                        }
-                        off[c] = nr + inc - n;
-                        nr += rl(inc, 63);
-                    }
-                    // write the items, count the code-length symbols
-#pragma unroll
-                    for (int c = 0; c < 5; ++c) {
-                        if (cnt[c]) {
-                            uint32_t r = run[c], o = off[c];
-                            const uint32_t v = Lv[c];
-                            if (v == 0) {
-                                uint32_t n18 = 0, n17 = 0, n0 = 0;
-                                while (r >= 11) {
-                                    const uint32_t t = r > 138 ? 138 : r;
-                                    rle[o++] = (uint16_t)(18 | ((t - 11) << 8));
-                                    ++n18;
-                                    r -= t;
-                                }
-                                if (r >= 3) {
-                                    rle[o++] = (uint16_t)(17 | ((r - 3) << 8));
-                                    ++n17;
-                                    r = 0;
-                                }
-                                while (r--) {
-                                    rle[o++] = 0;
-                                    ++n0;
-                                }
-                                if (n18) atomicAdd(&clf[18], n18);
-                                if (n17) atomicAdd(&clf[17], n17);
-                                if (n0) atomicAdd(&clf[0], n0);
-                            } else {
-                                uint32_t nv = 1, n16 = 0;
-                                rle[o++] = (uint16_t)v;
-                                --r;
-                                while (r >= 3) {
-                                    const uint32_t t = r > 6 ? 6 : r;
-                                    rle[o++] = (uint16_t)(16 | ((t - 3) << 8));
-                                    ++n16;
-                                    r -= t;
-                                }
-                                while (r--) {
-                                    rle[o++] = (uint16_t)v;
-                                    ++nv;
-                                }
-                                atomicAdd(&clf[v], nv);
-                                if (n16) atomicAdd(&clf[16], n16);
-                            }
-                        }
-                    }
-                    asm volatile("" ::: "memory");
-                    PH_END(5);
-                    // ---- code-length code (19 symbols, 7 bits) ----
-                    {
-                        uint32_t f = lane < 19 ? clf[lane] : 0u;
-                        const unsigned long long nz = __ballot(f != 0);
-                        if (__builtin_popcountll(nz) < 2 && ulane == ((nz & 1ull) ? 1u : 0u)) f = 1;
-                        uint32_t key = f ? ((f << 9) | ulane) : INF;
-                        key = wave_sort64(key);
-                        const uint32_t mC = (uint32_t)__builtin_popcountll(__ballot(key != INF));
-                        if (lane < 32) TD.sorted[lane] = key;
-                        asm volatile("" ::: "memory");
-                        wave_huffman<1>(TD, mC, 19, 7, cltab);
-                    }
-                    asm volatile("" ::: "memory");
-                    PH_END(6);
-                    // ---- header bits: every field is OR-merged into the staging words ----
-                    const uint32_t hb = bitpos - base_word * 32;  // bit offset of the header in stage[]
-                    auto put_bits = [&](uint32_t rel, uint32_t v, uint32_t nb) {
-                        // nb <= 17: at most two words
-                        const uint32_t w = rel >> 5, sh = rel & 31;
-                        const uint64_t x = (uint64_t)v << sh;
-                        atomicOr(&stage[w], (uint32_t)x);
-                        if (sh + nb > 32) atomicOr(&stage[w + 1], (uint32_t)(x >> 32));
-                    };
-                    uint32_t hclen;
-                    {
-                        // HCLEN order of the code-length symbols (RFC 1951 3.2.7), order[lane]:
-                        // 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15
-                        const uint64_t oa = 0x0609070800121110ull;  // order[0..7], one byte each
-                        const uint64_t ob = 0x020d030c040b050aull;  // order[8..15]
-                        const uint32_t oc = 0x000f010eu;            // order[16..18]
-                        uint32_t ord = 0;
-                        if (lane < 8)
-                            ord = (uint32_t)(oa >> (8 * ulane)) & 0xffu;
-                        else if (lane < 16)
-                            ord = (uint32_t)(ob >> (8 * (ulane - 8))) & 0xffu;
-                        else if (lane < 19)
-                            ord = (oc >> (8 * (ulane - 16))) & 0xffu;
-                        const uint32_t cll = lane < 19 ? cltab[ord] >> 16 : 0u;
-                        const unsigned long long mu = __ballot(cll != 0);
-                        hclen = 64 - (uint32_t)__builtin_clzll(mu | 1ull);
-                        if (hclen < 4) hclen = 4;
-                        if (lane == 0)
-                            put_bits(hb, bfinal | (2u << 1) | ((hlit - 257) << 3) | ((hdist - 1) << 8) | ((hclen - 4) << 13), 17);
-                        if (ulane < hclen) put_bits(hb + 17 + 3 * ulane, cll, 3);
-                    }
+                if (wave == 0) header_fields();
+                group_sync<NT>();
+            }
+            // stage[] holds the unit's partial last word at [0] and is zero elsewhere
+            const uint32_t hb = bitpos - base_word * 32;  // bit offset of the header in stage[]
+            if (wave == 0) {
+                auto put_bits = [&](uint32_t rel, uint32_t v, uint32_t nb) {
+                    // nb <= 17: at most two words
+                    const uint32_t w = rel >> 5, sh = rel & 31;
+                    const uint64_t x = (uint64_t)v << sh;
+                    atomicOr(&stage[w], (uint32_t)x);
+                    if (sh + nb > 32) atomicOr(&stage[w + 1], (uint32_t)(x >> 32));
+                };
+                const uint32_t ulane = (uint32_t)lane;
+                if (P.ctype == 2) {
+                    const uint32_t hlit = misc[M_META], hdist = misc[M_META + 1], hclen = misc[M_META + 2],
+                                   nr = misc[M_META + 3];
+                    const uint32_t cll = lane < 19 ? cltab[hclen_order(ulane)] >> 16 : 0u;
+                    if (lane == 0)
+                        put_bits(hb, bfinal | (2u << 1) | ((hlit - 257) << 3) | ((hdist - 1) << 8) | ((hclen - 4) << 13), 17);
+                    if (ulane < hclen) put_bits(hb + 17 + 3 * ulane, cll, 3);
                     uint32_t pos = hb + 17 + 3 * hclen;
 #pragma unroll
                     for (int c = 0; c < 5; ++c) {
@@ -1774,36 +1970,10 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
                         if (nb) put_bits(pos + inc - nb, v, nb);
                         pos += rl(inc, 63);
                     }
-                    if (lane == 0) misc[M_TMP] = pos;
-                }
-            } else {
-                // fixed Huffman codes (RFC 1951 3.2.6; FixedHuffmanTable rawdeflate.js:48-68)
-                for (int sy = tid; sy < 288; sy += EWG) {
-                    uint32_t c, l;
-                    if (sy <= 143) {
-                        c = 0x30 + sy;
-                        l = 8;
-                    } else if (sy <= 255) {
-                        c = 0x190 + sy - 144;
-                        l = 9;
-                    } else if (sy <= 279) {
-                        c = sy - 256;
-                        l = 7;
-                    } else {
-                        c = 0xc0 + sy - 280;
-                        l = 8;
-                    }
-                    lltab[sy] = (__brev(c) >> (32 - l)) | (l << 16);
-                }
-                if (tid < 32) dtab[tid] = (__brev((uint32_t)tid) >> 27) | (5u << 16);
-                if (tid == 0) {
-                    bw.put(bfinal, 1);
-                    bw.put(1, 2);
-                    misc[M_TMP] = bw.rel;
-                }
+                } else if (lane == 0)
+                    put_bits(hb, bfinal | (1u << 1), 3);
             }
-            group_sync<NT>();
-            bitpos = base_word * 32 + misc[M_TMP];
+            bitpos += misc[M_META + 4];
             group_sync<NT>();
             PH_END(7);
             // ---- emit tokens: four slots per thread and pass ----
@@ -1882,14 +2052,9 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
                 group_sync<NT>();
                 bitpos += total;
                 const uint32_t full = (bitpos >> 5) - base_word;
-                if (base_word + full <= cap_words) {
-                    for (uint32_t i = tid; i < full; i += EWG) {
-                        out32[base_word + i] = stage[i];
-                        stage[i] = 0;
-                    }
-                } else {
-                    for (uint32_t i = tid; i < full; i += EWG) stage[i] = 0;
-                    if (tid == 0) misc[M_OVF] = 1;
+                for (uint32_t i = tid; i < full; i += EWG) {
+                    if (fits) store_word(base_word + i, stage[i]);
+                    stage[i] = 0;
                 }
                 if (tid == 0 && full) {
                     stage[0] = stage[full];
@@ -1906,7 +2071,6 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
         if (tid == 0) {
             uint32_t bp = bitpos, cw = stage[0], bwd = base_word;
             stage[0] = 0;
-            bool ovf = misc[M_OVF] != 0;
             auto put = [&](uint32_t v, uint32_t nb) {
                 // serial writer straight to the output (at most a few words)
                 while (nb) {
@@ -1916,10 +2080,7 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
                     nb -= take;
                     bp += take;
                     if ((bp & 31) == 0) {
-                        if (bwd < cap_words)
-                            out32[bwd] = cw;
-                        else
-                            ovf = true;
+                        if (fits) store_word(bwd, cw);
                         ++bwd;
                         cw = 0;
                     }
@@ -1932,14 +2093,18 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
                 put(0xffff, 16);
             } else
                 put(0, (8 - (bp & 7)) & 7);
-            if (bp & 31) {
-                if (bwd < cap_words)
-                    out32[bwd] = cw;
-                else
-                    ovf = true;
+            if constexpr (DIRECT) {
+                if ((bp & 31) && fits) {
+                    // the last word is shared with the unit behind: bytewise, like a shared first word
+                    uint8_t *b = (uint8_t *)(out32 + bwd);
+                    for (uint32_t k = (bwd == 0 ? head : 0u); k < ((bp & 31) >> 3); ++k) b[k] = (uint8_t)(cw >> (8 * k));
+                }
+                P.status[u] = !placed ? 1u : !fits ? 2u : ((bp >> 3) - head != unit_bytes ? 1u : 0u);
+            } else {
+                if (bp & 31) store_word(bwd, cw);
+                P.out_size[u] = bp >> 3;
+                P.status[u] = misc[M_OVF] ? 1u : 0u;
             }
-            P.out_size[u] = bp >> 3;
-            P.status[u] = ovf ? 1u : 0u;
         }
         group_sync<NT>();
         PH_END(9);
@@ -1949,30 +2114,38 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(256, 8)
+extern "C" __global__ void __launch_bounds__(256, ZGPU_EMIT_WAVES)
 zgpu_emit_kernel(EParams P) {
     __shared__ __align__(16) uint8_t lds[emit_lds_bytes(256)];
-    emit_units<256>(P, lds);
+    emit_units<256, true>(P, lds);
 }
 // one wave per unit, four units per workgroup: chosen for rounds of small units
 extern "C" __global__ void __launch_bounds__(256, 4)
 zgpu_emit_small_kernel(EParams P) {
     __shared__ __align__(16) uint8_t lds[4 * emit_lds_bytes(64)];
-    emit_units<64>(P, lds + (threadIdx.x >> 6) * emit_lds_bytes(64));
+    emit_units<64, false>(P, lds + (threadIdx.x >> 6) * emit_lds_bytes(64));
+}
+// workgroup per unit into slots: plans that mix rounds of small units with rounds of larger ones
+extern "C" __global__ void __launch_bounds__(256, 8)
+zgpu_emit_slots_kernel(EParams P) {
+    __shared__ __align__(16) uint8_t lds[emit_lds_bytes(256)];
+    emit_units<256, false>(P, lds);
 }
 
 // ---- stored blocks (CompressionType.NONE; makeNocompressBlock rawdeflate.js:131-153)
+// The sizes follow from the unit sizes alone, so the host has the final offsets (slot_off) ready.
 extern "C" __global__ void __launch_bounds__(256)
 zgpu_stored_kernel(const uint8_t *in, const uint64_t *in_off, const uint64_t *slot_off,
-                   uint8_t *out_tmp, uint32_t *out_size, uint32_t *status, uint32_t n_units,
-                   uint32_t flags) {
+                   uint8_t *out, uint64_t out_cap, uint64_t *out_off, uint32_t *out_size, uint32_t *status,
+                   uint32_t n_units, uint32_t flags) {
     for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const uint8_t *src = in + in_off[u];
         const uint64_t n = in_off[u + 1] - in_off[u];
-        uint8_t *dst = out_tmp + slot_off[u];
+        const bool fits = slot_off[u + 1] <= out_cap;
+        uint8_t *dst = out + slot_off[u];
         const bool final_unit = (flags & 1u) || ((flags & 4u) && u == n_units - 1) || !(flags & 2u);
         const uint64_t nblk = n ? (n + 65534) / 65535 : 1;
-        for (uint64_t b = 0; b < nblk; ++b) {
+        for (uint64_t b = 0; fits && b < nblk; ++b) {
             const uint64_t o = b * 65535;
             const uint32_t len = (uint32_t)((n - o) < 65535 ? (n - o) : 65535);
             uint8_t *d = dst + b * 65540;
@@ -1987,7 +2160,9 @@ zgpu_stored_kernel(const uint8_t *in, const uint64_t *in_off, const uint64_t *sl
         }
         if (threadIdx.x == 0) {
             out_size[u] = (uint32_t)(n + 5 * nblk);
-            status[u] = 0;
+            out_off[u] = slot_off[u];
+            if (u + 1 == n_units) out_off[u + 1] = slot_off[u + 1];
+            status[u] = fits ? 0u : 2u;
         }
     }
 }

@@ -295,9 +295,10 @@ struct zgpu_plan {
     int ctype = 2, lazy = 0;
     uint32_t flags = 0;
     Knobs knobs{};
-    uint64_t in_total = 0, out_bound = 0, tmp_bytes = 0;
+    uint64_t in_total = 0, out_bound = 0;
     uint32_t n_pieces = 0;  // what the kernels see: units, the long ones cut into pieces
     bool split = false;     // some unit has more than one piece
+    bool direct = false;    // the emit kernel writes units at their final offsets (no staging, no gathering pass)
     // Unit tables: built on the host into one blob, uploaded with one copy.  The pointers below
     // point into d_tab.
     std::vector<uint8_t> h_tab;
@@ -312,7 +313,7 @@ struct zgpu_plan {
     uint32_t *d_first_seg = nullptr;   // n_units + 1
     DevBuf b_seg_crc, b_seg_adler;
     // results and workspace
-    DevBuf b_out_off, b_unit_out_off, b_out_size, b_status, b_crc, b_adler, b_counter, b_tok, b_hist, b_ntok, b_out_tmp;
+    DevBuf b_out_off, b_unit_out_off, b_out_size, b_status, b_crc, b_adler, b_counter, b_tok, b_hist, b_ntok, b_state, b_out_tmp;
     uint64_t *d_out_off() const { return b_out_off.as<uint64_t>(); }
     uint64_t *d_unit_out_off() const { return b_unit_out_off.as<uint64_t>(); }
     uint32_t *d_out_size() const { return b_out_size.as<uint32_t>(); }
@@ -328,7 +329,7 @@ struct zgpu_plan {
     bool pooled = false;  // owned by a device's host context (not counted as a caller's live plan)
     void release_buffers() {
         for (DevBuf *b : {&d_tab, &b_out_off, &b_unit_out_off, &b_out_size, &b_status, &b_crc, &b_adler, &b_counter, &b_tok,
-                          &b_hist, &b_ntok, &b_out_tmp, &b_seg_crc, &b_seg_adler})
+                          &b_hist, &b_ntok, &b_state, &b_out_tmp, &b_seg_crc, &b_seg_adler})
             b->release();
     }
 };
@@ -369,6 +370,33 @@ uint64_t unit_tok_cap(uint64_t n) {
     const uint64_t nb = unit_blocks(n), last = n - (nb - 1) * ZGPU_BLOCK_BYTES;
     return (nb - 1) * ZGPU_BLOCK_TOK + ((last + 1 + 3) & ~3ull) + 4;
 }
+
+// ---- host-buffer entry points: per-device staging kept from call to call ----------------
+// A batch in host memory is cut into sub-batches of about kSubBytes of input (32 MiB).  Four slots per
+// device (stream, input buffer, plan with its workspace) take them in turn, each driven by its
+// own host thread: the upload of one sub-batch runs while another is compressed and a third is
+// fetched, so PCIe and the kernels overlap.  Nothing here is allocated per call once the
+// buffers have grown to the caller's batch size.
+constexpr int kMaxSlots = 8;
+// tuning overrides (read once): ZGPU_SUB_BYTES, ZGPU_SLOTS
+const uint64_t kSubBytes = [] {
+    const char *e = getenv("ZGPU_SUB_BYTES");
+    const uint64_t v = e ? strtoull(e, nullptr, 10) : 0;
+    return v >= (1ull << 20) ? v : (32ull << 20);
+}();
+constexpr uint64_t kStageMaxBytes = 3ull << 30;
+// the search kernel's half-window variant (two workgroups per CU) serves rounds of units of at most 16 KiB;
+// ZGPU_HALF_WINDOW=1 / 0 forces it on / off for measurements
+const int kHalfWindow = [] {
+    const char *e = getenv("ZGPU_HALF_WINDOW");
+    return e ? (e[0] == '1' ? 1 : 0) : -1;
+}();
+constexpr uint64_t kHalfWindowMax = 16384;
+// rounds whose units are all at most this long take the wave-per-unit emit kernel (ZGPU_EMIT_SMALL_MAX tunes)
+const uint64_t kEmitSmallMax = [] {
+    const char *e = getenv("ZGPU_EMIT_SMALL_MAX");
+    return e ? strtoull(e, nullptr, 10) : (16ull << 10);
+}();
 
 // (Re)targets a plan at a unit table: builds the piece / slot / token tables, grows the
 // workspace where it is too small and uploads the tables on `st`.  history: bytes of the same
@@ -433,12 +461,15 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
     p->split = n_pieces != n_units;
     std::vector<uint64_t> slot(n_pieces + 1);
     uint64_t acc = 0;
+    // Stored blocks have sizes that follow from the unit sizes, so their final offsets are ready here.
+    // For the Huffman modes the slots are bounds: what a caller must provide to be sure of room, and
+    // -- for plans that stage their output (see p->direct) -- where a unit goes before it is placed.
     for (uint32_t i = 0; i < n_pieces; ++i) {
         slot[i] = acc;
-        acc += align_up(zgpu_deflate_bound(pc_off[i + 1] - pc_off[i]) + 32, 16);
+        const uint64_t n = pc_off[i + 1] - pc_off[i];
+        acc += ctype == ZGPU_NONE ? n + 5 * (n ? (n + 65534) / 65535 : 1) : align_up(zgpu_deflate_bound(n) + 32, 16);
     }
     slot[n_pieces] = acc;
-    p->tmp_bytes = acc;
     p->out_bound = acc;
     // Token scratch: 2 bytes per input byte in the worst case.  Pieces are cut into rounds
     // whose tokens fit a buffer of at most a third of the free device memory (ZGPU_TOK_BYTES
@@ -472,6 +503,12 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
         }
         p->rounds.push_back({first, n_pieces, round_max});
     }
+    // Units go straight to their final offsets (sizes first, a look-back for the offsets) unless the
+    // plan has a round of small units: thousands of those are in flight at once, and a look-back per
+    // unit then costs more than staging the small output in slots and gathering it.
+    p->direct = ctype != ZGPU_NONE;
+    for (const auto &r : p->rounds)
+        if (r.max_bytes <= kEmitSmallMax) p->direct = false;
     // ---- checksum segments (only when a unit is longer than a segment) ----
     std::vector<uint64_t> seg_off;
     std::vector<uint32_t> first_seg;
@@ -535,7 +572,8 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
     ENS(p->b_crc, (size_t)n_units * 4);
     ENS(p->b_adler, (size_t)n_units * 4);
     ENS(p->b_counter, (p->rounds.size() * 2 + 2) * 4);
-    ENS(p->b_out_tmp, p->tmp_bytes + 64);
+    if (p->direct) ENS(p->b_state, (size_t)n_pieces * 8);
+    if (ctype != ZGPU_NONE && !p->direct) ENS(p->b_out_tmp, acc + 64);
     if (ctype != ZGPU_NONE) {
         ENS(p->b_tok, (size_t)tok_buf_tokens * 2 + 64);
         ENS(p->b_hist, (size_t)n_blocks * 320 * 4);
@@ -573,32 +611,6 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
     return ZGPU_OK;
 }
 
-// ---- host-buffer entry points: per-device staging kept from call to call ----------------
-// A batch in host memory is cut into sub-batches of about kSubBytes of input (32 MiB).  Four slots per
-// device (stream, input buffer, plan with its workspace) take them in turn, each driven by its
-// own host thread: the upload of one sub-batch runs while another is compressed and a third is
-// fetched, so PCIe and the kernels overlap.  Nothing here is allocated per call once the
-// buffers have grown to the caller's batch size.
-constexpr int kMaxSlots = 8;
-// tuning overrides (read once): ZGPU_SUB_BYTES, ZGPU_SLOTS
-const uint64_t kSubBytes = [] {
-    const char *e = getenv("ZGPU_SUB_BYTES");
-    const uint64_t v = e ? strtoull(e, nullptr, 10) : 0;
-    return v >= (1ull << 20) ? v : (32ull << 20);
-}();
-constexpr uint64_t kStageMaxBytes = 3ull << 30;
-// the search kernel's half-window variant (two workgroups per CU) serves rounds of units of at most 16 KiB;
-// ZGPU_HALF_WINDOW=1 / 0 forces it on / off for measurements
-const int kHalfWindow = [] {
-    const char *e = getenv("ZGPU_HALF_WINDOW");
-    return e ? (e[0] == '1' ? 1 : 0) : -1;
-}();
-constexpr uint64_t kHalfWindowMax = 16384;
-// rounds whose units are all at most this long take the wave-per-unit emit kernel (ZGPU_EMIT_SMALL_MAX tunes)
-const uint64_t kEmitSmallMax = [] {
-    const char *e = getenv("ZGPU_EMIT_SMALL_MAX");
-    return e ? strtoull(e, nullptr, 10) : (16ull << 10);
-}();
 const int kSlots = [] {
     const char *e = getenv("ZGPU_SLOTS");
     const int v = e ? atoi(e) : 0;
@@ -1041,16 +1053,17 @@ uint64_t zgpu_plan_out_bound(const zgpu_plan *p) { return p ? p->out_bound : 0; 
 
 int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap, void *stream_) {
     if (!p || !d_out || (!d_in && p->in_total)) return ZGPU_E_ARG;
+    if ((uintptr_t)d_out & 3) return ZGPU_E_ARG;  // units that share a 32-bit word with a neighbour are stitched bytewise
     hipStream_t st = (hipStream_t)stream_;
     HIPCHK(hipEventRecord(p->ev[0], st));
     HIPCHK(hipMemsetAsync(p->d_counter(), 0, (p->rounds.size() * 2 + 2) * 4, st));
+    if (p->direct) HIPCHK(hipMemsetAsync(p->b_state.p, 0, (size_t)p->n_pieces * 8, st));
     HIPCHK(hipEventRecord(p->ev[1], st));
-    uint8_t *d_out_tmp = p->b_out_tmp.as<uint8_t>();
     if (p->ctype == ZGPU_NONE) {
         int grid = p->n_units < (uint32_t)p->ds->cus * 8 ? (int)p->n_units : p->ds->cus * 8;
         hipLaunchKernelGGL(zgpu_stored_kernel, dim3(grid), dim3(256), 0, st, (const uint8_t *)d_in,
-                           p->d_in_off, p->d_slot_off, d_out_tmp, p->d_out_size(), p->d_status(),
-                           p->n_units, p->flags);
+                           p->d_in_off, p->d_slot_off, (uint8_t *)d_out, out_cap, p->d_out_off(), p->d_out_size(),
+                           p->d_status(), p->n_units, p->flags);
         HIPCHK(hipEventRecord(p->ev[4], st));
     } else {
         for (size_t r = 0; r < p->rounds.size(); ++r) {
@@ -1088,8 +1101,12 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             if (r == 0) HIPCHK(hipEventRecord(p->ev[4], st));
             EParams E;
             E.in_off = p->d_in_off;
+            E.out = p->direct ? (uint8_t *)d_out : p->b_out_tmp.as<uint8_t>();
+            E.out_cap = out_cap;
             E.slot_off = p->d_slot_off;
-            E.out_tmp = d_out_tmp;
+            E.out_off = p->d_out_off();
+            E.state = p->b_state.as<unsigned long long>();
+            E.n_total = p->n_pieces;
             E.out_size = p->d_out_size();
             E.status = p->d_status();
             E.tok = p->b_tok.as<uint16_t>();
@@ -1109,19 +1126,20 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
                 hipLaunchKernelGGL(zgpu_emit_small_kernel, dim3(wgs < emax ? wgs : emax), dim3(256), 0, st, E);
             } else {
                 const uint32_t emax = (uint32_t)p->ds->cus * ZGPU_EMIT_WG_PER_CU;
-                hipLaunchKernelGGL(zgpu_emit_kernel, dim3(cnt < emax ? cnt : emax), dim3(256), 0, st, E);
+                if (p->direct)
+                    hipLaunchKernelGGL(zgpu_emit_kernel, dim3(cnt < emax ? cnt : emax), dim3(256), 0, st, E);
+                else
+                    hipLaunchKernelGGL(zgpu_emit_slots_kernel, dim3(cnt < emax ? cnt : emax), dim3(256), 0, st, E);
             }
         }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(p->ev[2], st));
-    hipLaunchKernelGGL(zgpu_scan_kernel, dim3(1), dim3(1024), 0, st, p->d_out_size(), p->d_out_off(),
-                       p->n_pieces);
-    {
+    if (p->ctype != ZGPU_NONE && !p->direct) {
+        hipLaunchKernelGGL(zgpu_scan_kernel, dim3(1), dim3(1024), 0, st, p->d_out_size(), p->d_out_off(), p->n_pieces);
         int grid = p->n_pieces < (uint32_t)p->ds->cus * 8 ? (int)p->n_pieces : p->ds->cus * 8;
-        hipLaunchKernelGGL(zgpu_compact_kernel, dim3(grid), dim3(256), 0, st, d_out_tmp,
-                           p->d_slot_off, p->d_out_off(), (uint8_t *)d_out, out_cap, p->d_status(),
-                           p->n_pieces);
+        hipLaunchKernelGGL(zgpu_compact_kernel, dim3(grid), dim3(256), 0, st, p->b_out_tmp.as<uint8_t>(), p->d_slot_off,
+                           p->d_out_off(), (uint8_t *)d_out, out_cap, p->d_status(), p->n_pieces);
     }
     if (p->split)
         hipLaunchKernelGGL(zgpu_unit_offsets_kernel, dim3(p->n_units / 256 + 1), dim3(256), 0, st, p->d_out_off(),
