@@ -88,6 +88,12 @@ struct CfgHalf {  // 16 KiB ring halves: two workgroups per CU (the occupancy ex
     static constexpr uint32_t RING = 32768, CHAIN = 16384, HBITS = ZGPU_HALF_HBITS, NSLOT = 32, NSLOT_E = 64, LAG = 24;
 };
 
+struct CfgQuarter {  // units of at most 4 KiB: four workgroups of eight waves per CU, 8 Ki chain slots
+    static constexpr int WG = 512;
+    static constexpr int WG_PER_CU = 4;
+    static constexpr uint32_t RING = 16384, CHAIN = 8192, HBITS = 10, NSLOT = 16, NSLOT_E = 32, LAG = 12;
+};
+
 constexpr uint32_t huf_scratch_bytes(uint32_t cap) { return 17 * cap + 128; }  // see HufS
 
 // ---- LDS map of the search kernel (bytes) ------------------------------------
@@ -570,7 +576,9 @@ struct Params {
     uint32_t *counter;          // unit queue head (relative to unit_first)
     uint32_t unit_first, unit_end;
     int lazy, max_chain, nice;
-    int deep, fan;              // long-match steps: deep-walk budget, probe-ahead fans per item (0 = off)
+    int deep, fan;
+    const uint32_t *unit_list;  // NULL: units unit_first .. unit_end; else list_len unit numbers (and unit_end = ~0)
+    uint32_t list_len;              // long-match steps: deep-walk budget, probe-ahead fans per item (0 = off)
     const uint32_t *unit_prime; // per unit: bytes before it (same stream, multiple of 64, <= 32 KiB) that prime its window
     unsigned long long *prof;   // 16 phase counters (diagnostic builds) or null
 };
@@ -612,7 +620,10 @@ __device__ __forceinline__ void search_units(const Params &P) {
     // costs no global round trips (they are three dependent ones: ticket, offsets, data, and
     // with one workgroup per CU nothing else would hide them), only the load of its first bytes.
     auto fetch_unit = [&](uint32_t tag) {
-        const uint32_t nu = P.unit_first + atomicAdd(P.counter, 1u);
+        // the queue hands out a range of units, or -- when a round's units are spread over kernel
+        // variants by size -- the entries of a list
+        const uint32_t ticket = atomicAdd(P.counter, 1u);
+        const uint32_t nu = P.unit_list ? (ticket < P.list_len ? P.unit_list[ticket] : 0xffffffffu) : P.unit_first + ticket;
         uint64_t uo = 0, to = 0;
         uint32_t nn = 0, prm = 0, bf = 0;
         if (nu < P.unit_end) {
@@ -1403,6 +1414,7 @@ extern "C" __global__ void __launch_bounds__(1024) zgpu_deflate_kernel(Params P)
 extern "C" __global__ void __launch_bounds__(1024) zgpu_deflate_thorough_kernel(Params P) { search_units<true, CfgFull>(P); }
 // the occupancy experiment: half the window, two workgroups (32 waves) per CU, 64 registers per lane
 extern "C" __global__ void __launch_bounds__(1024, 8) zgpu_deflate_half_kernel(Params P) { search_units<false, CfgHalf>(P); }
+extern "C" __global__ void __launch_bounds__(512, 8) zgpu_deflate_quarter_kernel(Params P) { search_units<false, CfgQuarter>(P); }
 
 namespace {
 

@@ -321,7 +321,10 @@ struct zgpu_plan {
     uint32_t *d_crc() const { return b_crc.as<uint32_t>(); }
     uint32_t *d_adler() const { return b_adler.as<uint32_t>(); }
     uint32_t *d_counter() const { return b_counter.as<uint32_t>(); }
-    struct Round { uint32_t first, end; uint64_t max_bytes; };
+    // cls_len[c] > 0: the units of size class c (0: up to kQuarterMax, 1: up to kHalfWindowMax, 2: longer) are
+    // listed at d_list + cls_at[c]; all zero: the round is of one class (by max_bytes) and runs as a range
+    struct Round { uint32_t first, end; uint64_t max_bytes; uint32_t cls_at[3] = {0, 0, 0}, cls_len[3] = {0, 0, 0}; };
+    uint32_t *d_list = nullptr;
     std::vector<Round> rounds;  // units whose tokens share the token buffer at one time
     std::vector<uint32_t> h_status;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -392,6 +395,12 @@ const int kHalfWindow = [] {
     return e ? (e[0] == '1' ? 1 : 0) : -1;
 }();
 constexpr uint64_t kHalfWindowMax = 16384;
+// ... and units of at most this many bytes the four-workgroups-per-CU variant, whose window is 7040 bytes
+// (ZGPU_QUARTER_MAX tunes)
+const uint64_t kQuarterMax = [] {
+    const char *e = getenv("ZGPU_QUARTER_MAX");
+    return e ? strtoull(e, nullptr, 10) : 8192ull;
+}();
 // rounds whose units are all at most this long take the wave-per-unit emit kernel (ZGPU_EMIT_SMALL_MAX tunes)
 const uint64_t kEmitSmallMax = [] {
     const char *e = getenv("ZGPU_EMIT_SMALL_MAX");
@@ -503,6 +512,24 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
         }
         p->rounds.push_back({first, n_pieces, round_max});
     }
+    // ---- size classes: a round whose units differ in class is searched by one launch per class, each over
+    // a list of unit numbers (the variants with smaller windows run more workgroups per CU, and a unit that
+    // fits the smaller window loses nothing to it)
+    std::vector<uint32_t> lists;
+    if (ctype != ZGPU_NONE && kHalfWindow < 0 && p->knobs.nice <= 32) {
+        auto cls_of = [](uint64_t n) { return n <= kQuarterMax ? 0 : n <= kHalfWindowMax ? 1 : 2; };
+        for (auto &r : p->rounds) {
+            uint32_t cnt[3] = {0, 0, 0};
+            for (uint32_t i = r.first; i < r.end; ++i) ++cnt[cls_of(pc_off[i + 1] - pc_off[i])];
+            if ((cnt[0] != 0) + (cnt[1] != 0) + (cnt[2] != 0) < 2) continue;
+            for (int c = 0; c < 3; ++c) {
+                r.cls_at[c] = (uint32_t)lists.size();
+                r.cls_len[c] = cnt[c];
+                for (uint32_t i = r.first; i < r.end; ++i)
+                    if (cls_of(pc_off[i + 1] - pc_off[i]) == c) lists.push_back(i);
+            }
+        }
+    }
     // Units go straight to their final offsets (sizes first, a look-back for the offsets) unless the
     // plan has a round of small units: thousands of those are in flight at once, and a look-back per
     // unit then costs more than staging the small output in slots and gathering it.
@@ -545,7 +572,7 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
                  o_uin = place(p->split ? (size_t)(n_units + 1) * 8 : 0),
                  o_fp = place(p->split ? (size_t)(n_units + 1) * 4 : 0),
                  o_seg = place(p->n_segs ? (size_t)(p->n_segs + 1) * 8 : 0),
-                 o_fseg = place(p->n_segs ? (size_t)(n_units + 1) * 4 : 0);
+                 o_fseg = place(p->n_segs ? (size_t)(n_units + 1) * 4 : 0), o_list = place(lists.size() * 4);
     p->h_tab.resize(off);
     uint8_t *h = p->h_tab.data();
     memcpy(h + o_in, pc_off.data(), (size_t)(n_pieces + 1) * 8);
@@ -558,6 +585,7 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
         memcpy(h + o_uin, in_off, (size_t)(n_units + 1) * 8);
         memcpy(h + o_fp, first_piece.data(), (size_t)(n_units + 1) * 4);
     }
+    if (!lists.empty()) memcpy(h + o_list, lists.data(), lists.size() * 4);
     if (p->n_segs) {
         memcpy(h + o_seg, seg_off.data(), (size_t)(p->n_segs + 1) * 8);
         memcpy(h + o_fseg, first_seg.data(), (size_t)(n_units + 1) * 4);
@@ -571,7 +599,7 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
     ENS(p->b_status, (size_t)n_pieces * 4);
     ENS(p->b_crc, (size_t)n_units * 4);
     ENS(p->b_adler, (size_t)n_units * 4);
-    ENS(p->b_counter, (p->rounds.size() * 2 + 2) * 4);
+    ENS(p->b_counter, (p->rounds.size() * 4 + 2) * 4);
     if (p->direct) ENS(p->b_state, (size_t)n_pieces * 8);
     if (ctype != ZGPU_NONE && !p->direct) ENS(p->b_out_tmp, acc + 64);
     if (ctype != ZGPU_NONE) {
@@ -594,6 +622,7 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
     p->d_final = d + o_final;
     p->d_unit_in_off = (uint64_t *)(d + o_uin);
     p->d_first_piece = (uint32_t *)(d + o_fp);
+    p->d_list = (uint32_t *)(d + o_list);
     p->d_seg_off = (uint64_t *)(d + o_seg);
     p->d_first_seg = (uint32_t *)(d + o_fseg);
     if (async) {
@@ -1056,7 +1085,7 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
     if ((uintptr_t)d_out & 3) return ZGPU_E_ARG;  // units that share a 32-bit word with a neighbour are stitched bytewise
     hipStream_t st = (hipStream_t)stream_;
     HIPCHK(hipEventRecord(p->ev[0], st));
-    HIPCHK(hipMemsetAsync(p->d_counter(), 0, (p->rounds.size() * 2 + 2) * 4, st));
+    HIPCHK(hipMemsetAsync(p->d_counter(), 0, (p->rounds.size() * 4 + 2) * 4, st));
     if (p->direct) HIPCHK(hipMemsetAsync(p->b_state.p, 0, (size_t)p->n_pieces * 8, st));
     HIPCHK(hipEventRecord(p->ev[1], st));
     if (p->ctype == ZGPU_NONE) {
@@ -1076,9 +1105,6 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             P.blk_first = p->d_blk_first;
             P.hist = p->b_hist.as<uint32_t>();
             P.ntok = p->b_ntok.as<uint32_t>();
-            P.counter = p->d_counter() + 2 * r;
-            P.unit_first = first;
-            P.unit_end = end;
             // the caller's lazy is the threshold below which a match is deferred when the next
             // position matches longer; min_lazy (default 258: always) is its floor
             P.lazy = p->lazy > p->knobs.min_lazy ? p->lazy : p->knobs.min_lazy;
@@ -1088,16 +1114,42 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             P.fan = p->knobs.fan;
             P.unit_prime = p->d_prime;
             P.prof = g_prof;
-            int sgrid = (int)(cnt < (uint32_t)p->ds->cus ? cnt : (uint32_t)p->ds->cus);
-            if ((kHalfWindow == 1 || (kHalfWindow < 0 && p->rounds[r].max_bytes <= kHalfWindowMax)) && p->knobs.nice <= 32) {
-                // units that fit half a window lose nothing to it: two workgroups per CU, 32 waves
-                // (ZGPU_HALF_WINDOW=1 forces the variant for any unit size, =0 never takes it)
-                sgrid = (int)(cnt < 2 * (uint32_t)p->ds->cus ? cnt : 2 * (uint32_t)p->ds->cus);
-                hipLaunchKernelGGL(zgpu_deflate_half_kernel, dim3(sgrid), dim3(1024), 0, st, P);
-            } else if (p->knobs.nice > 32)
-                hipLaunchKernelGGL(zgpu_deflate_thorough_kernel, dim3(sgrid), dim3(1024), 0, st, P);
-            else
-                hipLaunchKernelGGL(zgpu_deflate_kernel, dim3(sgrid), dim3(1024), 0, st, P);
+            // one launch over the round's range, or one per size class over its list
+            const auto &R = p->rounds[r];
+            const bool listed = R.cls_len[0] + R.cls_len[1] + R.cls_len[2] != 0;
+            for (int c = 0; c < 3; ++c) {
+                uint32_t n_here = cnt;
+                int cls = c;
+                P.counter = p->d_counter() + 4 * r + c;
+                if (listed) {
+                    if (!R.cls_len[c]) continue;
+                    n_here = R.cls_len[c];
+                    P.unit_list = p->d_list + R.cls_at[c];
+                    P.list_len = n_here;
+                    P.unit_first = 0;
+                    P.unit_end = 0xffffffffu;
+                } else {
+                    if (c) break;
+                    P.unit_list = nullptr;
+                    P.list_len = 0;
+                    P.unit_first = first;
+                    P.unit_end = end;
+                    // ZGPU_HALF_WINDOW=1 forces the half-window variant for any unit size, =0 the full window
+                    cls = kHalfWindow == 1 ? 1 : kHalfWindow == 0 ? 2 : R.max_bytes <= kQuarterMax ? 0 : R.max_bytes <= kHalfWindowMax ? 1 : 2;
+                }
+                const uint32_t cus = (uint32_t)p->ds->cus;
+                if (p->knobs.nice > 32) {
+                    hipLaunchKernelGGL(zgpu_deflate_thorough_kernel, dim3(n_here < cus ? n_here : cus), dim3(1024), 0, st, P);
+                } else if (cls == 0) {
+                    // tiny units: a unit's few items keep eight waves busy as well as sixteen, and four units
+                    // per CU are in flight instead of two
+                    hipLaunchKernelGGL(zgpu_deflate_quarter_kernel, dim3(n_here < 4 * cus ? n_here : 4 * cus), dim3(512), 0, st, P);
+                } else if (cls == 1) {
+                    // units that fit half a window lose nothing to it: two workgroups per CU, 32 waves
+                    hipLaunchKernelGGL(zgpu_deflate_half_kernel, dim3(n_here < 2 * cus ? n_here : 2 * cus), dim3(1024), 0, st, P);
+                } else
+                    hipLaunchKernelGGL(zgpu_deflate_kernel, dim3(n_here < cus ? n_here : cus), dim3(1024), 0, st, P);
+            }
             if (r == 0) HIPCHK(hipEventRecord(p->ev[4], st));
             EParams E;
             E.in_off = p->d_in_off;
@@ -1114,7 +1166,7 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             E.blk_first = p->d_blk_first;
             E.hist = p->b_hist.as<uint32_t>();
             E.ntok = p->b_ntok.as<uint32_t>();
-            E.counter = p->d_counter() + 2 * r + 1;
+            E.counter = p->d_counter() + 4 * r + 3;
             E.unit_first = first;
             E.unit_end = end;
             E.unit_final = p->d_final;
