@@ -62,15 +62,16 @@ def main():
     # (search + emit kernels).  FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE
     # reports half the bytes of wide (16 B per lane) streaming reads, so it is doubled.
     try:
-        f_kb = sum(out["fetch"][k]["FETCH_SIZE"] for k in ("zgpu_deflate_kernel", "zgpu_emit_kernel"))
-        w_kb = sum(out["write"][k]["WRITE_SIZE"] for k in ("zgpu_deflate_kernel", "zgpu_emit_kernel"))
+        # every kernel of a zgpu_plan_run (the bench's own verifier is not one)
+        f_kb = sum(v["FETCH_SIZE"] for k, v in out["fetch"].items() if k != "zgpu_verify_kernel")
+        w_kb = sum(v["WRITE_SIZE"] for k, v in out["write"].items() if k != "zgpu_verify_kernel")
         traffic = {
             "workload": {"units": 65536, "unit_bytes": 65536, "ctype": 2, "lazy": 0},
             "bytes_per_launch": int((2 * f_kb + w_kb) * 1024),
             "fetch_size_kb_raw": f_kb, "write_size_kb_raw": w_kb,
-            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), sum of zgpu_deflate_kernel and "
-                    "zgpu_emit_kernel, FETCH_SIZE doubled (gfx950 counts 128-B read requests at 64 B); the token "
-                    "stream between the two kernels is part of it",
+            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), sum over the kernels of one "
+                    "zgpu_plan_run (search and emit; no gathering pass any more), FETCH_SIZE doubled (gfx950 counts "
+                    "128-B read requests at 64 B); the token stream between the two kernels is part of it",
             "source": "%s_pmc.json" % tag,
         }
         # LDS side of the search kernel (sq1 / sq2 passes, 8192 units of the same mix): share of the
