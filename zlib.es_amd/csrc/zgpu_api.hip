@@ -374,20 +374,7 @@ uint64_t unit_tok_cap(uint64_t n) {
     return (nb - 1) * ZGPU_BLOCK_TOK + ((last + 1 + 3) & ~3ull) + 4;
 }
 
-// ---- host-buffer entry points: per-device staging kept from call to call ----------------
-// A batch in host memory is cut into sub-batches of about kSubBytes of input (32 MiB).  Four slots per
-// device (stream, input buffer, plan with its workspace) take them in turn, each driven by its
-// own host thread: the upload of one sub-batch runs while another is compressed and a third is
-// fetched, so PCIe and the kernels overlap.  Nothing here is allocated per call once the
-// buffers have grown to the caller's batch size.
-constexpr int kMaxSlots = 8;
-// tuning overrides (read once): ZGPU_SUB_BYTES, ZGPU_SLOTS
-const uint64_t kSubBytes = [] {
-    const char *e = getenv("ZGPU_SUB_BYTES");
-    const uint64_t v = e ? strtoull(e, nullptr, 10) : 0;
-    return v >= (1ull << 20) ? v : (32ull << 20);
-}();
-constexpr uint64_t kStageMaxBytes = 3ull << 30;
+// ---- which kernel variant serves which units (thresholds read once) ----------------------
 // the search kernel's half-window variant (two workgroups per CU) serves rounds of units of at most 16 KiB;
 // ZGPU_HALF_WINDOW=1 / 0 forces it on / off for measurements
 const int kHalfWindow = [] {
@@ -640,6 +627,20 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
     return ZGPU_OK;
 }
 
+// ---- host-buffer entry points: per-device staging kept from call to call ----------------
+// A batch in host memory is cut into sub-batches of about kSubBytes of input (32 MiB).  Four slots per
+// device (stream, input buffer, plan with its workspace) take them in turn, each driven by its
+// own host thread: the upload of one sub-batch runs while another is compressed and a third is
+// fetched, so PCIe and the kernels overlap.  Nothing here is allocated per call once the
+// buffers have grown to the caller's batch size.
+constexpr int kMaxSlots = 8;
+// tuning overrides (read once): ZGPU_SUB_BYTES, ZGPU_SLOTS
+const uint64_t kSubBytes = [] {
+    const char *e = getenv("ZGPU_SUB_BYTES");
+    const uint64_t v = e ? strtoull(e, nullptr, 10) : 0;
+    return v >= (1ull << 20) ? v : (32ull << 20);
+}();
+constexpr uint64_t kStageMaxBytes = 3ull << 30;
 const int kSlots = [] {
     const char *e = getenv("ZGPU_SLOTS");
     const int v = e ? atoi(e) : 0;
