@@ -58,7 +58,10 @@ constexpr uint32_t WMASK = 0x7fff;  // chain slots (32 Ki positions)
 constexpr int PEND = 2;             // searched items a wave may hold before it must parse the oldest
 constexpr uint32_t LAG = 48;        // an item starts only when all items more than LAG back are parsed
 constexpr uint32_t FAN_MAXDIST = 16;  // probe-ahead fans start from matches at most this far back
-constexpr uint32_t AHEAD = 4;         // the chains are linked this many items ahead of the search
+#ifndef ZGPU_AHEAD
+#define ZGPU_AHEAD 4
+#endif
+constexpr uint32_t AHEAD = ZGPU_AHEAD;         // the chains are linked this many items ahead of the search
 constexpr uint32_t MAXDIST = 32768 - 64 * (LAG + AHEAD) - 128;  // window minus the span of in-flight items
 constexpr uint32_t BLK_ITEMS = 1024;  // one DEFLATE block per 64 KiB of input
 constexpr uint32_t LOOKAHEAD = 64 + 6 * 64 + 258 + 16;  // bytes an item may read past its start
