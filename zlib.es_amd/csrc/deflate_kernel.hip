@@ -1149,7 +1149,8 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     // better than the nearest long candidate.  The reference looks at every earlier
                     // occurrence and keeps the longest (src/rawdeflate.js:370-395); two bounded
                     // steps go after the same matches here.
-                    if ((P.deep > 0 || P.fan > 0) && __ballot(blen >= CMP_CAP && blen < maxlen)) {
+                    const int fans = AHEAD ? P.fan : 0;  // the fan reads links of positions ahead: only with run-ahead linking
+                    if ((P.deep > 0 || fans > 0) && __ballot(blen >= CMP_CAP && blen < maxlen)) {
                         // exact length (up to 258) of the match of position px at distance d, px and d
                         // uniform: four bytes per lane, first differing lane by ballot
                         auto coop_len = [&](uint32_t px, uint32_t d, uint32_t mx) -> uint32_t {
@@ -1267,7 +1268,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         // later place -- the alignments that matter where repeats of different
                         // lengths follow each other (runs, records)
                         unsigned long long fanned = 0;
-                        for (int f = 0; f < P.fan; ++f) {
+                        for (int f = 0; f < fans; ++f) {
                             // only where the match repeats at a short distance (a run, a short period): that
                             // is where a longer match hides behind thousands of equally near candidates
                             const unsigned long long sm = starts() & ~fanned & __ballot(best_dist <= FAN_MAXDIST);
