@@ -59,7 +59,7 @@ constexpr int PEND = 2;             // searched items a wave may hold before it 
 constexpr uint32_t LAG = 48;        // an item starts only when all items more than LAG back are parsed
 constexpr uint32_t FAN_MAXDIST = 16;  // probe-ahead fans start from matches at most this far back
 #ifndef ZGPU_AHEAD
-#define ZGPU_AHEAD 4
+#define ZGPU_AHEAD 0
 #endif
 constexpr uint32_t AHEAD = ZGPU_AHEAD;         // the chains are linked this many items ahead of the search
 constexpr uint32_t MAXDIST = 32768 - 64 * (LAG + AHEAD) - 128;  // window minus the span of in-flight items
@@ -1149,7 +1149,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     // better than the nearest long candidate.  The reference looks at every earlier
                     // occurrence and keeps the longest (src/rawdeflate.js:370-395); two bounded
                     // steps go after the same matches here.
-                    const int fans = AHEAD ? P.fan : 0;  // the fan reads links of positions ahead: only with run-ahead linking
+                    const int fans = P.fan;
                     if ((P.deep > 0 || fans > 0) && __ballot(blen >= CMP_CAP && blen < maxlen)) {
                         // exact length (up to 258) of the match of position px at distance d, px and d
                         // uniform: four bytes per lane, first differing lane by ballot
@@ -1273,6 +1273,18 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             // is where a longer match hides behind thousands of equally near candidates
                             const unsigned long long sm = starts() & ~fanned & __ballot(best_dist <= FAN_MAXDIST);
                             if (!sm) break;
+                            // The probes read links of positions up to 256 bytes on: those of the next four
+                            // items of the block.  Without run-ahead linking they are waited for here, by the
+                            // few waves that come this far: the items are in other waves' hands or will be
+                            // taken by the waves that finish next, and linking an item waits for nothing this
+                            // wave holds, so the wait ends.  The horizon is a function of the item number
+                            // alone: the output does not depend on timing.
+                            uint32_t horizon = 0xffffffffu;
+                            if constexpr (AHEAD == 0) {
+                                const uint32_t hz = k + 5u < blk_end ? k + 5u : blk_end;
+                                if (f == 0) lds_wait_ge(&misc[M_LINKED], hz);
+                                horizon = hz << 6;
+                            }
                             const uint32_t sl = (uint32_t)__builtin_ctzll(sm);
                             fanned |= 1ull << sl;
                             const uint32_t px = p0 + sl, cur = rl(blen, sl), mx = rl(maxlen, sl), lim = rl(limit, sl);
@@ -1280,7 +1292,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             // lane i probes the link of position px + j, j = cur - 3 + 4 i
                             const uint32_t j = cur - 3u + ((uint32_t)lane << 2);
                             const uint32_t q = px + j;
-                            bool ok = j + 4u <= mx;
+                            bool ok = j + 4u <= mx && q < horizon;
                             uint32_t d = 0;
                             if (ok) {
                                 const uint32_t c2 = prevt[q & WMASK];
