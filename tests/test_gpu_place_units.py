@@ -28,6 +28,9 @@ def _units(kind):
     if kind == "large+tiny":  # still the direct path (one unit above 16 KiB is enough), many units inside one 32-bit word
         sizes = [20000] + [int(x) for x in rng.integers(0, 12, 400)] + [70000, 0, 0, 1, 30000]
         return [zo.gen({"gen": gens[i % 4], "n": n, "seed": i}) for i, n in enumerate(sizes)]
+    if kind == "mixed":  # mostly small units by bytes, so staged; the few large ones are emitted from their own list
+        sizes = [int(x) for x in rng.integers(0, 3000, 300)] + [150000] + [int(x) for x in rng.integers(9000, 16000, 40)] + [70000, 5, 0]
+        return [zo.gen({"gen": gens[i % 4], "n": n, "seed": i}) for i, n in enumerate(sizes)]
     return [zo.gen({"gen": gens[i % 4], "n": int(n), "seed": i}) for i, n in enumerate(rng.integers(0, 3000, 700))]  # staged
 
 
@@ -47,7 +50,7 @@ def _run(z, torch, units, ctype, cap=None, guard=64):
     return rc, off.astype(np.int64), host
 
 
-@pytest.mark.parametrize("kind", ["large", "large+tiny", "small"])
+@pytest.mark.parametrize("kind", ["large", "large+tiny", "small", "mixed"])
 @pytest.mark.parametrize("ctype", [1, 2])
 def test_units_land_back_to_back_and_nothing_else_is_written(env, kind, ctype):
     z, torch = env
@@ -66,7 +69,7 @@ def test_units_land_back_to_back_and_nothing_else_is_written(env, kind, ctype):
     assert np.all(host2[total:] == 0xA5)
 
 
-@pytest.mark.parametrize("kind", ["large", "small"])
+@pytest.mark.parametrize("kind", ["large", "small", "mixed"])
 def test_units_beyond_the_capacity_are_left_out_and_reported(env, kind):
     z, torch = env
     units = _units(kind)

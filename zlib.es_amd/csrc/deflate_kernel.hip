@@ -1472,6 +1472,8 @@ struct EParams {
     uint32_t *counter;         // unit queue head (relative to unit_first)
     const uint8_t *unit_final; // n_units: 1 = the unit ends its stream (BFINAL), 0 = it ends with an empty stored block
     uint32_t unit_first, unit_end, n_total;
+    const uint32_t *unit_list;  // NULL: units unit_first .. unit_end; else list_len unit numbers (and unit_end = ~0)
+    uint32_t list_len;
     int ctype;
     unsigned long long *prof;  // diagnostic builds: 16 per-phase cycle sums of each unit's thread 0
 };
@@ -1874,7 +1876,11 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
     };
 
     for (;;) {
-        if (tid == 0) misc[M_UNIT] = P.unit_first + atomicAdd(P.counter, 1u);
+        if (tid == 0) {
+            // a range of units, or the entries of a list (a round emitted per size class)
+            const uint32_t ticket = atomicAdd(P.counter, 1u);
+            misc[M_UNIT] = P.unit_list ? (ticket < P.list_len ? P.unit_list[ticket] : 0xffffffffu) : P.unit_first + ticket;
+        }
         group_sync<NT>();
         const uint32_t u = misc[M_UNIT];
         group_sync<NT>();

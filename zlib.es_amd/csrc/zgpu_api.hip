@@ -299,6 +299,7 @@ struct zgpu_plan {
     uint32_t n_pieces = 0;  // what the kernels see: units, the long ones cut into pieces
     bool split = false;     // some unit has more than one piece
     bool direct = false;    // the emit kernel writes units at their final offsets (no staging, no gathering pass)
+    bool search_by_class = false;  // the search kernel's small-window variants take the units that fit them
     // Unit tables: built on the host into one blob, uploaded with one copy.  The pointers below
     // point into d_tab.
     std::vector<uint8_t> h_tab;
@@ -421,13 +422,23 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
     // A unit's pieces are consecutive, so its output is their concatenation.
     const bool chunked = (flags & ZGPU_F_SYNC_ALIGN) && !(flags & ZGPU_F_FINAL_EACH);
     const bool prime_units = chunked && (flags & ZGPU_F_PRIME_WINDOW);
-    // Piece size: a batch with fewer units than kPiecesPerCu per CU (the unit queue then balances
+    // Piece size: a batch with fewer large units than kPiecesPerCu per CU (the unit queue then balances
     // poorly at its tail, and the emit kernel's workgroups run short) cuts units longer than two
-    // pieces into pieces of total / (kPiecesPerCu x CUs) bytes, between 128 KiB and the set limit.
+    // pieces into pieces of (their bytes) / (kPiecesPerCu x CUs), between 128 KiB and the set limit.
     constexpr uint32_t kPiecesPerCu = 16;
     uint64_t piece = 0;
-    if (ctype != ZGPU_NONE && p->knobs.split && n_units < kPiecesPerCu * (uint32_t)ds->cus) {
-        piece = align_up((in_off[n_units] - in_off[0]) / ((uint64_t)kPiecesPerCu * (uint64_t)ds->cus) + 1, 65536);
+    // Counted over the units above 16 KiB: the smaller ones run in the small-window kernel variants, several
+    // to a CU, and do not help to fill the CUs the large ones leave idle.
+    uint64_t n_big = 0, big_bytes = 0;
+    for (uint32_t i = 0; i < n_units; ++i) {
+        const uint64_t n = in_off[i + 1] - in_off[i];
+        if (n > kHalfWindowMax) {
+            ++n_big;
+            big_bytes += n;
+        }
+    }
+    if (ctype != ZGPU_NONE && p->knobs.split && n_big && n_big < kPiecesPerCu * (uint64_t)ds->cus) {
+        piece = align_up(big_bytes / ((uint64_t)kPiecesPerCu * (uint64_t)ds->cus) + 1, 65536);
         if (piece < (128u << 10)) piece = 128u << 10;
         if (piece > p->knobs.split) piece = p->knobs.split;
     }
@@ -503,7 +514,8 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
     // a list of unit numbers (the variants with smaller windows run more workgroups per CU, and a unit that
     // fits the smaller window loses nothing to it)
     std::vector<uint32_t> lists;
-    if (ctype != ZGPU_NONE && kHalfWindow < 0 && p->knobs.nice <= 32) {
+    p->search_by_class = kHalfWindow < 0 && p->knobs.nice <= 32;
+    if (ctype != ZGPU_NONE) {
         auto cls_of = [](uint64_t n) { return n <= kQuarterMax ? 0 : n <= kHalfWindowMax ? 1 : 2; };
         for (auto &r : p->rounds) {
             uint32_t cnt[3] = {0, 0, 0};
@@ -517,12 +529,20 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
             }
         }
     }
-    // Units go straight to their final offsets (sizes first, a look-back for the offsets) unless the
-    // plan has a round of small units: thousands of those are in flight at once, and a look-back per
+    // Units go straight to their final offsets (sizes first, a look-back for the offsets) unless much of the
+    // plan is small units: thousands of those are in flight at once, and a look-back per
     // unit then costs more than staging the small output in slots and gathering it.
-    p->direct = ctype != ZGPU_NONE;
-    for (const auto &r : p->rounds)
-        if (r.max_bytes <= kEmitSmallMax) p->direct = false;
+    // Decided by bytes: a few small files beside large ones ride along in the direct path, a large file
+    // among many small ones is staged like them.
+    {
+        uint64_t small_bytes = 0;
+        for (uint32_t i = 0; i < n_pieces; ++i) {
+            const uint64_t n = pc_off[i + 1] - pc_off[i];
+            if (n <= kEmitSmallMax) small_bytes += n ? n : 1;
+        }
+        p->direct = ctype != ZGPU_NONE && small_bytes * 8 <= pc_off[n_pieces] - pc_off[0];
+        if (small_bytes == 0) p->direct = ctype != ZGPU_NONE;
+    }
     // ---- checksum segments (only when a unit is longer than a segment) ----
     std::vector<uint64_t> seg_off;
     std::vector<uint32_t> first_seg;
@@ -586,7 +606,7 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
     ENS(p->b_status, (size_t)n_pieces * 4);
     ENS(p->b_crc, (size_t)n_units * 4);
     ENS(p->b_adler, (size_t)n_units * 4);
-    ENS(p->b_counter, (p->rounds.size() * 4 + 2) * 4);
+    ENS(p->b_counter, (p->rounds.size() * 6 + 2) * 4);
     if (p->direct) ENS(p->b_state, (size_t)n_pieces * 8);
     if (ctype != ZGPU_NONE && !p->direct) ENS(p->b_out_tmp, acc + 64);
     if (ctype != ZGPU_NONE) {
@@ -1086,7 +1106,7 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
     if ((uintptr_t)d_out & 3) return ZGPU_E_ARG;  // units that share a 32-bit word with a neighbour are stitched bytewise
     hipStream_t st = (hipStream_t)stream_;
     HIPCHK(hipEventRecord(p->ev[0], st));
-    HIPCHK(hipMemsetAsync(p->d_counter(), 0, (p->rounds.size() * 4 + 2) * 4, st));
+    HIPCHK(hipMemsetAsync(p->d_counter(), 0, (p->rounds.size() * 6 + 2) * 4, st));
     if (p->direct) HIPCHK(hipMemsetAsync(p->b_state.p, 0, (size_t)p->n_pieces * 8, st));
     HIPCHK(hipEventRecord(p->ev[1], st));
     if (p->ctype == ZGPU_NONE) {
@@ -1117,11 +1137,12 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             P.prof = g_prof;
             // one launch over the round's range, or one per size class over its list
             const auto &R = p->rounds[r];
-            const bool listed = R.cls_len[0] + R.cls_len[1] + R.cls_len[2] != 0;
+            const bool has_lists = R.cls_len[0] + R.cls_len[1] + R.cls_len[2] != 0;
+            const bool listed = has_lists && p->search_by_class;
             for (int c = 0; c < 3; ++c) {
                 uint32_t n_here = cnt;
                 int cls = c;
-                P.counter = p->d_counter() + 4 * r + c;
+                P.counter = p->d_counter() + 6 * r + c;
                 if (listed) {
                     if (!R.cls_len[c]) continue;
                     n_here = R.cls_len[c];
@@ -1136,7 +1157,7 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
                     P.unit_first = first;
                     P.unit_end = end;
                     // ZGPU_HALF_WINDOW=1 forces the half-window variant for any unit size, =0 the full window
-                    cls = kHalfWindow == 1 ? 1 : kHalfWindow == 0 ? 2 : R.max_bytes <= kQuarterMax ? 0 : R.max_bytes <= kHalfWindowMax ? 1 : 2;
+                    cls = kHalfWindow == 1 ? 1 : (kHalfWindow == 0 || has_lists) ? 2 : R.max_bytes <= kQuarterMax ? 0 : R.max_bytes <= kHalfWindowMax ? 1 : 2;
                 }
                 const uint32_t cus = (uint32_t)p->ds->cus;
                 if (p->knobs.nice > 32) {
@@ -1167,22 +1188,42 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             E.blk_first = p->d_blk_first;
             E.hist = p->b_hist.as<uint32_t>();
             E.ntok = p->b_ntok.as<uint32_t>();
-            E.counter = p->d_counter() + 4 * r + 3;
-            E.unit_first = first;
-            E.unit_end = end;
             E.unit_final = p->d_final;
             E.ctype = p->ctype;
             E.prof = g_prof ? g_prof + 16 : nullptr;
-            if (p->rounds[r].max_bytes <= kEmitSmallMax) {
-                // small units: one wave per unit, four units per workgroup, four workgroups per CU
-                const uint32_t wgs = (cnt + 3) / 4, emax = (uint32_t)p->ds->cus * 4;
-                hipLaunchKernelGGL(zgpu_emit_small_kernel, dim3(wgs < emax ? wgs : emax), dim3(256), 0, st, E);
-            } else {
-                const uint32_t emax = (uint32_t)p->ds->cus * ZGPU_EMIT_WG_PER_CU;
-                if (p->direct)
-                    hipLaunchKernelGGL(zgpu_emit_kernel, dim3(cnt < emax ? cnt : emax), dim3(256), 0, st, E);
-                else
-                    hipLaunchKernelGGL(zgpu_emit_slots_kernel, dim3(cnt < emax ? cnt : emax), dim3(256), 0, st, E);
+            // one launch over the round's range; a staged round with units of several size classes is
+            // emitted per class: the small ones a wave each, the others a workgroup each
+            const bool by_class = has_lists && !p->direct;
+            for (int c = 0; c < 3; ++c) {
+                uint32_t n_here = cnt;
+                bool small = R.max_bytes <= kEmitSmallMax;
+                E.counter = p->d_counter() + 6 * r + 3 + c;
+                if (by_class) {
+                    if (!R.cls_len[c]) continue;
+                    n_here = R.cls_len[c];
+                    small = c < 2;
+                    E.unit_list = p->d_list + R.cls_at[c];
+                    E.list_len = n_here;
+                    E.unit_first = 0;
+                    E.unit_end = 0xffffffffu;
+                } else {
+                    if (c) break;
+                    E.unit_list = nullptr;
+                    E.list_len = 0;
+                    E.unit_first = first;
+                    E.unit_end = end;
+                }
+                if (small && !p->direct) {
+                    // small units: one wave per unit, four units per workgroup, four workgroups per CU
+                    const uint32_t wgs = (n_here + 3) / 4, emax = (uint32_t)p->ds->cus * 4;
+                    hipLaunchKernelGGL(zgpu_emit_small_kernel, dim3(wgs < emax ? wgs : emax), dim3(256), 0, st, E);
+                } else {
+                    const uint32_t emax = (uint32_t)p->ds->cus * ZGPU_EMIT_WG_PER_CU;
+                    if (p->direct)
+                        hipLaunchKernelGGL(zgpu_emit_kernel, dim3(n_here < emax ? n_here : emax), dim3(256), 0, st, E);
+                    else
+                        hipLaunchKernelGGL(zgpu_emit_slots_kernel, dim3(n_here < emax ? n_here : emax), dim3(256), 0, st, E);
+                }
             }
         }
     }
