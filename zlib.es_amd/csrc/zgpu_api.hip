@@ -1193,7 +1193,7 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             E.prof = g_prof ? g_prof + 16 : nullptr;
             // one launch over the round's range; a staged round with units of several size classes is
             // emitted per class: the small ones a wave each, the others a workgroup each
-            const bool by_class = has_lists && !p->direct;
+            const bool by_class = has_lists && !p->direct && R.cls_len[2] != 0;  // all small: one launch does
             for (int c = 0; c < 3; ++c) {
                 uint32_t n_here = cnt;
                 bool small = R.max_bytes <= kEmitSmallMax;
