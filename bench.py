@@ -340,7 +340,7 @@ def bench_deflate(ctx, workload, short=False):
         # read the input once, write the compressed stream once; the path is two kernels
         # (match search, then Huffman coding + bit emission), priced together
         algo_bytes = in_bytes + out_bytes
-        # rounds whose largest unit is at most 16 KiB run the two-workgroups-per-CU search variant and the
+        # units of at most 16 KiB run in the search variants with several workgroups per CU and the
         # wave-per-unit emit variant
         small_units = all(int((np.diff(np.asarray(g[0])).max() if len(g[0]) > 1 else 0)) <= 16384 for g in groups)
         traffic, traffic_src = measured_traffic(workload, cfg, args)
@@ -348,7 +348,8 @@ def bench_deflate(ctx, workload, short=False):
                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                            "traffic": traffic, "traffic_source": traffic_src,
-                           "kernel": ("zgpu_deflate_half_kernel + zgpu_emit_small_kernel" if small_units else
+                           "kernel": ("zgpu_deflate_quarter_kernel (units up to 8 KiB) / zgpu_deflate_half_kernel + "
+                                      "zgpu_emit_small_kernel" if small_units else
                                       "zgpu_deflate_kernel + zgpu_emit_kernel"), "kernel_ms": round(k_ms, 3),
                            "search_kernel_ms": round(search_ms, 3), "emit_kernel_ms": round(emit_ms, 3),
                            "timing": "HIP events recorded by the library on the run's stream around the kernels of "
