@@ -43,6 +43,7 @@ typedef struct {
     int fan_try;      /* passing candidates verified per fan, farthest j first (0 = all) */
     int fan_from0;    /* 1: probes start at j = 0 instead of at the tail of the current best */
     int fan_maxd;     /* a lane fans only when its best distance is at most this (0 = any) */
+    int fan_depth;    /* links followed along the chain of each probed position (0 = 1) */
     int itemfast;     /* 1: an item whose 64 positions all repeat at lane 0's nearest candidate distance takes that distance and skips the search */
 } Policy;
 static uint64_t g_fans, g_fast;
@@ -483,11 +484,13 @@ static uint64_t simulate(uint32_t n, const Policy *P, int ctype, uint64_t *walk_
                     uint32_t j = j0 + (uint32_t)P->fan_stride * i;
                     if (j + 4 > maxlen) break;
                     int32_t c2 = prevp[p + j];
-                    if (c2 < 0) continue;
-                    uint32_t d = p + j - (uint32_t)c2;
-                    if (d > limit) continue;
-                    if (memcmp(data + p - d, data + p, 4) || memcmp(data + c2, data + p + j, 4)) continue;
-                    pass_d[npass++] = d;
+                    for (int dep = 0; dep < (P->fan_depth ? P->fan_depth : 1) && c2 >= 0; ++dep, c2 = prevp[c2]) {
+                        uint32_t d = p + j - (uint32_t)c2;
+                        if (d > limit) break;
+                        if (memcmp(data + p - d, data + p, 4) || memcmp(data + c2, data + p + j, 4)) continue;
+                        if (npass < 64) pass_d[npass++] = d;
+                        break; /* the nearest one of this chain that lines up */
+                    }
                 }
                 uint32_t newd = 0;
                 int tries = 0;
@@ -582,7 +585,7 @@ int main(int argc, char **argv) {
     };
     const int ncases = sizeof cases / sizeof cases[0];
     /* policies: name=value pairs on the command line override the round-1 defaults */
-    Policy P = {8, 32, 1, 16, 6, 0, 0, 0, 258, 4096, 0, 0, 1, 0, 0, 32, 4, 0, 0, 0, 0};
+    Policy P = {8, 32, 1, 16, 6, 0, 0, 0, 258, 4096, 0, 0, 1, 0, 0, 32, 4, 0, 0, 0, 0, 0};
     for (int a = 1; a < argc; ++a) {
         char key[32];
         int v;
@@ -590,7 +593,7 @@ int main(int argc, char **argv) {
 #define K(name) if (!strcmp(key, #name)) P.name = v
         K(chain); K(cap); K(stop_at_cap); K(share_min); K(share_iters); K(share_order); K(keep); K(deep);
         K(lazy); K(min3dist); K(dist1); K(exact_own); K(start_only); K(tail_all);
-        K(fan); K(fan_min); K(fan_stride); K(fan_try); K(fan_from0); K(fan_maxd); K(itemfast);
+        K(fan); K(fan_min); K(fan_stride); K(fan_try); K(fan_from0); K(fan_maxd); K(fan_depth); K(itemfast);
 #undef K
     }
     g_dump = getenv("DUMP") != NULL;
