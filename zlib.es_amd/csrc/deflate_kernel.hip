@@ -167,16 +167,38 @@ struct Lds {
     __device__ uint8_t *scr() const { return base + L_SCR; }
 };
 
+// 16 bytes at a global address of any alignment: the two aligned 16-byte pieces that hold them, shifted
+// into place.  Both pieces contain bytes that were asked for, so nothing outside the pages of the
+// caller's buffer is touched.  (Units of a ragged batch -- zip entries -- start at any byte.)
+__device__ inline uint4 ldg16_any(const uint8_t *p) {
+    const uint32_t a = (uint32_t)((uintptr_t)p & 15u);
+    const uint4 *g = (const uint4 *)(p - a);
+    const uint4 x = g[0];
+    if (a == 0) return x;
+    const uint4 y = g[1];
+    const uint32_t r = a & 3u;
+    uint32_t w0, w1, w2, w3, w4;
+    switch (a >> 2) {
+    case 0: w0 = x.x, w1 = x.y, w2 = x.z, w3 = x.w, w4 = y.x; break;
+    case 1: w0 = x.y, w1 = x.z, w2 = x.w, w3 = y.x, w4 = y.y; break;
+    case 2: w0 = x.z, w1 = x.w, w2 = y.x, w3 = y.y, w4 = y.z; break;
+    default: w0 = x.w, w1 = y.x, w2 = y.y, w3 = y.z, w4 = y.w; break;
+    }
+    return make_uint4(__builtin_amdgcn_alignbyte(w1, w0, r), __builtin_amdgcn_alignbyte(w2, w1, r),
+                      __builtin_amdgcn_alignbyte(w3, w2, r), __builtin_amdgcn_alignbyte(w4, w3, r));
+}
+
 // input bytes [lo, hi) of the unit -> ring (and the mirror of its first bytes);
-// lo is a multiple of 16.  `nthreads` threads with ids `t` cooperate.
+// lo is a multiple of 16.  `nthreads` threads with ids `t` cooperate.  `aligned`: the unit starts at a
+// multiple of 16 bytes (one load per 16 bytes instead of two and a shift).
 template <uint32_t RING>
 __device__ inline void load_ring(uint8_t *ring, const uint8_t *in, uint32_t lo, uint32_t hi, int t,
                                  int nthreads, bool aligned) {
     uint32_t done = lo;
-    if (aligned) {
+    {
         const uint32_t hi16 = lo + ((hi - lo) & ~15u);
         for (uint32_t p = lo + (uint32_t)t * 16; p < hi16; p += (uint32_t)nthreads * 16) {
-            const uint4 v = *(const uint4 *)(in + p);
+            const uint4 v = aligned ? *(const uint4 *)(in + p) : ldg16_any(in + p);
             const uint32_t ri = p & (RING - 1);
             *(uint4 *)(ring + ri) = v;
             if (ri < RING_PAD) *(uint4 *)(ring + RING + ri) = v;
@@ -1398,10 +1420,8 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     const uint32_t npr = misc[M_NEXT + 4];
                     const uint8_t *nin = P.in + ((uint64_t)misc[M_NEXT + 1] | (uint64_t)misc[M_NEXT + 2] << 32) - npr;
                     const uint32_t nn = misc[M_NEXT + 3] + npr;
-                    if ((((uintptr_t)nin) & 15u) == 0) {
-                        pf_hi = (nn < REFILL ? nn : REFILL) & ~15u;
-                        if ((uint32_t)tid * 16u < pf_hi) pf = *(const uint4 *)(nin + tid * 16);
-                    }
+                    pf_hi = (nn < REFILL ? nn : REFILL) & ~15u;
+                    if ((uint32_t)tid * 16u < pf_hi) pf = ldg16_any(nin + tid * 16);
                 }
             }
             while (npend > 0) emit_oldest(blk_end, true);
