@@ -51,7 +51,7 @@ def _run(z, torch, units, ctype, cap=None, guard=64):
 
 
 @pytest.mark.parametrize("kind", ["large", "large+tiny", "small", "mixed"])
-@pytest.mark.parametrize("ctype", [1, 2])
+@pytest.mark.parametrize("ctype", [0, 1, 2])
 def test_units_land_back_to_back_and_nothing_else_is_written(env, kind, ctype):
     z, torch = env
     units = _units(kind)

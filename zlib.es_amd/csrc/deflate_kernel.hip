@@ -2210,7 +2210,21 @@ zgpu_stored_kernel(const uint8_t *in, const uint64_t *in_off, const uint64_t *sl
                 d[3] = ~len & 0xff;
                 d[4] = (~len >> 8) & 0xff;
             }
-            for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) d[5 + i] = src[o + i];
+            // payload: bytes up to a 4-byte boundary of the destination, then dwords put together from the
+            // two source dwords that hold them (source and destination are aligned differently), then the tail
+            uint8_t *d0 = d + 5;
+            const uint8_t *s0 = src + o;
+            uint32_t headn = (4u - (uint32_t)((uintptr_t)d0 & 3u)) & 3u;
+            if (headn > len) headn = len;
+            if (threadIdx.x < headn) d0[threadIdx.x] = s0[threadIdx.x];
+            const uint32_t body = (len - headn) & ~3u;
+            const uint8_t *sb = s0 + headn;
+            uint32_t *dw = (uint32_t *)(d0 + headn);
+            const uint32_t sa = (uint32_t)((uintptr_t)sb & 3u);
+            const uint32_t *sw = (const uint32_t *)(sb - sa);
+            for (uint32_t i = threadIdx.x; i < body / 4; i += blockDim.x)
+                dw[i] = sa ? __builtin_amdgcn_alignbyte(sw[i + 1], sw[i], sa) : sw[i];
+            for (uint32_t i = headn + body + threadIdx.x; i < len; i += blockDim.x) d0[i] = s0[i];
         }
         if (threadIdx.x == 0) {
             out_size[u] = (uint32_t)(n + 5 * nblk);
