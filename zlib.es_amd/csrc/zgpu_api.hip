@@ -382,7 +382,11 @@ const int kHalfWindow = [] {
     const char *e = getenv("ZGPU_HALF_WINDOW");
     return e ? (e[0] == '1' ? 1 : 0) : -1;
 }();
-constexpr uint64_t kHalfWindowMax = 16384;
+// units of at most this many bytes take the half-window variant (window 14,464 bytes; ZGPU_HALF_MAX tunes)
+const uint64_t kHalfWindowMax = [] {
+    const char *e = getenv("ZGPU_HALF_MAX");
+    return e ? strtoull(e, nullptr, 10) : 16384ull;
+}();
 // ... and units of at most this many bytes the four-workgroups-per-CU variant, whose window is 7040 bytes
 // (ZGPU_QUARTER_MAX tunes)
 const uint64_t kQuarterMax = [] {
