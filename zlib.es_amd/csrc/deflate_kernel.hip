@@ -738,9 +738,9 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 P.ntok[gb] = nt + 1;
                 misc[M_NTOK] = 0;
             }
-            if (tid < 320) {
-                P.hist[(size_t)gb * 320 + tid] = tid == 256 ? 1u : fl[tid];  // fl[288] + fd[32] are adjacent
-                fl[tid] = 0;
+            for (int i = tid; i < 320; i += WG) {  // a variant's workgroup may have fewer threads than counters
+                P.hist[(size_t)gb * 320 + i] = i == 256 ? 1u : fl[i];  // fl[288] + fd[32] are adjacent
+                fl[i] = 0;
             }
             __syncthreads();
         };
@@ -1303,7 +1303,10 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             // alone: the output does not depend on timing.
                             uint32_t horizon = 0xffffffffu;
                             if constexpr (AHEAD == 0) {
-                                const uint32_t hz = k + 5u < blk_end ? k + 5u : blk_end;
+                                // as many items on as the workgroup has waves, at most: were all its waves
+                                // waiting here with consecutive items, the oldest must find its items linked
+                                constexpr uint32_t FAN_ITEMS = WG / 64 < 5 ? WG / 64 : 5;
+                                const uint32_t hz = k + FAN_ITEMS < blk_end ? k + FAN_ITEMS : blk_end;
                                 if (f == 0) lds_wait_ge(&misc[M_LINKED], hz);
                                 horizon = hz << 6;
                             }
