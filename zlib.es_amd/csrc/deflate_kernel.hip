@@ -76,25 +76,34 @@ constexpr int SHARE_ITERS_THOROUGH = 16;  // ... and when the walk goes on past 
 // The constants above describe the full-window variant: one 1024-thread workgroup per CU with a
 // 64 KiB ring and 32 Ki chain slots.  SearchCfg gathers what a variant may change; the kernel body
 // reads its geometry from the variant's SearchCfg only.
+#ifndef ZGPU_LAG_FULL
+#define ZGPU_LAG_FULL 48
+#endif
+#ifndef ZGPU_LAG_HALF
+#define ZGPU_LAG_HALF 30
+#endif
+#ifndef ZGPU_LAG_QUARTER
+#define ZGPU_LAG_QUARTER 12
+#endif
 struct CfgFull {  // 32 KiB window, one workgroup per CU
     static constexpr int WG = 1024;
     static constexpr int WG_PER_CU = 1;
-    static constexpr uint32_t RING = 65536, CHAIN = 32768, HBITS = 13, NSLOT = 64, NSLOT_E = 128, LAG = 48;
+    static constexpr uint32_t RING = 65536, CHAIN = 32768, HBITS = 13, NSLOT = 64, NSLOT_E = 128, LAG = ZGPU_LAG_FULL;
 };
 #ifndef ZGPU_HALF_HBITS
 #define ZGPU_HALF_HBITS 11
 #define ZGPU_HALF_WGS 2
 #endif
-struct CfgHalf {  // 16 KiB ring halves: two workgroups per CU (the occupancy experiment)
+struct CfgHalf {  // units of at most 16 KiB: two workgroups per CU, 16 Ki chain slots
     static constexpr int WG = 1024;
     static constexpr int WG_PER_CU = ZGPU_HALF_WGS;
-    static constexpr uint32_t RING = 32768, CHAIN = 16384, HBITS = ZGPU_HALF_HBITS, NSLOT = 32, NSLOT_E = 64, LAG = 24;
+    static constexpr uint32_t RING = 32768, CHAIN = 16384, HBITS = ZGPU_HALF_HBITS, NSLOT = 32, NSLOT_E = 64, LAG = ZGPU_LAG_HALF;
 };
 
 struct CfgQuarter {  // units of at most 4 KiB: four workgroups of eight waves per CU, 8 Ki chain slots
     static constexpr int WG = 512;
     static constexpr int WG_PER_CU = 4;
-    static constexpr uint32_t RING = 16384, CHAIN = 8192, HBITS = 10, NSLOT = 16, NSLOT_E = 32, LAG = 12;
+    static constexpr uint32_t RING = 16384, CHAIN = 8192, HBITS = 10, NSLOT = 16, NSLOT_E = 32, LAG = ZGPU_LAG_QUARTER;
 };
 
 constexpr uint32_t huf_scratch_bytes(uint32_t cap) { return 17 * cap + 128; }  // see HufS
@@ -631,6 +640,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
     static_assert(REFILL >= LOOKAHEAD && NSLOT > LAG && NSLOT_E > 2 * LAG, "geometry");
     // a refill may overwrite what lies a ring behind its end while the item LAG back still searches its window
     static_assert(MAXDIST + 64 * LAG + 2 * REFILL <= RING, "ring holds the window");
+    static_assert(NSLOT > LAG && NSLOT_E > 2 * LAG, "parse-table rings hold the items in flight");
     __shared__ __align__(16) uint8_t lds_raw[L_TOTAL];
     const int tid = threadIdx.x, lane = tid & 63;
     uint8_t *ring = lds_raw + L_RING;
