@@ -43,26 +43,36 @@ __device__ inline uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) {
 
 // tables: [0..16*256) slice tables Tk[b] = crc state of byte b followed by k
 // zero bytes; [16*256..20*256) advance tables Sj[v] = (v << 8j) advanced by
-// 16*T bytes; [20*256..20*256+8) x^(128*d) for d = 1,2,4,..,128.
-extern "C" __global__ void __launch_bounds__(ZGPU_CK_THREADS)
-zgpu_checksum_kernel(const uint8_t *in, const uint64_t *seg_off, uint32_t n_segs,
-                     const uint32_t *tables, uint32_t *out_crc, uint32_t *out_adler) {
-    __shared__ uint32_t tab[20 * 256];
+// 16*256 bytes; [20*256..20*256+8) x^(128*d) for d = 1,2,4,..,128; then (wave variant)
+// 4*256 advance tables for 16*64 bytes.
+// NT threads share a segment: the workgroup (256), or one wave (64; four segments side by side
+// in a workgroup, no barrier inside the loop: batches of small units, whose time is the chain of
+// round trips and the fold rather than their bytes).
+template <int NT>
+__device__ __forceinline__ void checksum_segments(const uint8_t *in, const uint64_t *seg_off, uint32_t n_segs,
+                                                  const uint32_t *tables, uint32_t *out_crc, uint32_t *out_adler) {
+    __shared__ uint32_t tab[(NT == 64 ? 24 : 20) * 256];
     __shared__ uint32_t xpow[8];
     __shared__ uint32_t red_crc[T / 64];
     __shared__ unsigned long long red_sb[T / 64], red_sw[T / 64];
+    __shared__ __align__(16) uint32_t tailw[T / 64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 20 * 256; i += T) tab[i] = tables[i];
+    if (NT == 64)
+        for (int i = tid; i < 4 * 256; i += T) tab[20 * 256 + i] = tables[20 * 256 + 8 + i];
     if (tid < 8) xpow[tid] = tables[20 * 256 + tid];
     __syncthreads();
-    const uint32_t *S = tab + 16 * 256;
+    const uint32_t *S = tab + (NT == 64 ? 20 : 16) * 256;  // advance by 16 * NT bytes
+    const int t = NT == 64 ? lane : tid;                     // index within the group that shares a segment
+    const uint32_t first = NT == 64 ? blockIdx.x * (T / 64) + wave : blockIdx.x;
+    const uint32_t stride = NT == 64 ? gridDim.x * (T / 64) : gridDim.x;
 
-    for (uint32_t sg = blockIdx.x; sg < n_segs; sg += gridDim.x) {
+    for (uint32_t sg = first; sg < n_segs; sg += stride) {
         const uint64_t o = seg_off[sg], n = seg_off[sg + 1] - o;
         const uint8_t *p0 = in + o;
         uint32_t crc_state;
         unsigned long long sb = 0, sw = 0;  // sum b, sum q*b
-        uint64_t tail_lo, tail_hi;          // byte range finished serially by thread 0
+        uint64_t tail_lo, tail_hi;          // byte range finished serially by the group's first thread
         uint32_t B = 0;
         if (n < 64) {
             tail_lo = 0;
@@ -72,12 +82,12 @@ zgpu_checksum_kernel(const uint8_t *in, const uint64_t *seg_off, uint32_t n_segs
             const uint32_t a = (uint32_t)((uintptr_t)p0 & 15u);
             const uint8_t *vstart = p0 - a;
             const uint64_t kv = (a + n) >> 4;  // full 16-byte pieces (first may start before p0)
-            const uint32_t pad = (uint32_t)((T - (kv % T)) % T);
-            const uint64_t rounds = (kv + pad) / T;
+            const uint32_t pad = (uint32_t)((NT - (kv % NT)) % NT);
+            const uint64_t rounds = (kv + pad) / NT;
             uint32_t A = 0;
             for (uint64_t r = 0; r < rounds; ++r) {
-                const int64_t i = (int64_t)(r * T + tid) - (int64_t)pad;
-                // advance by 16*T bytes
+                const int64_t i = (int64_t)(r * NT + t) - (int64_t)pad;
+                // advance by 16*NT bytes
                 A = S[A & 0xff] ^ S[256 + ((A >> 8) & 0xff)] ^ S[512 + ((A >> 16) & 0xff)] ^
                     S[768 + (A >> 24)];
                 if (i >= 0) {
@@ -124,47 +134,66 @@ zgpu_checksum_kernel(const uint8_t *in, const uint64_t *seg_off, uint32_t n_segs
                     A ^= c;
                 }
             }
-            // fold the 256 lane remainders: lane t must be advanced by 16*(T-1-t) bytes
+            // fold the lane remainders: lane t must be advanced by 16*(NT-1-t) bytes
 #pragma unroll
             for (int d = 1, lv = 0; d < 64; d <<= 1, ++lv) {
                 const uint32_t other = __shfl_down(A, d, 64);
                 if ((lane & (2 * d - 1)) == 0) A = gf_mul(A, xpow[lv]) ^ other;
             }
-            if (lane == 0) red_crc[wave] = A;
-            __syncthreads();
-            if (tid == 0) {
-                uint32_t x = red_crc[0];
-                x = gf_mul(x, xpow[6]) ^ red_crc[1];
-                uint32_t y = red_crc[2];
-                y = gf_mul(y, xpow[6]) ^ red_crc[3];
-                B = gf_mul(x, xpow[7]) ^ y;
-            }
+            if constexpr (NT == 256) {
+                if (lane == 0) red_crc[wave] = A;
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t x = red_crc[0];
+                    x = gf_mul(x, xpow[6]) ^ red_crc[1];
+                    uint32_t y = red_crc[2];
+                    y = gf_mul(y, xpow[6]) ^ red_crc[3];
+                    B = gf_mul(x, xpow[7]) ^ y;
+                }
+            } else
+                B = A;  // lane 0 holds the wave's remainder
             crc_state = B;
             tail_lo = kv * 16 - a;
             tail_hi = n;
         }
-        // Adler partial sums across the workgroup
+        // Adler partial sums across the group
         for (int d = 32; d > 0; d >>= 1) {
             sb += __shfl_down(sb, d, 64);
             sw += __shfl_down(sw, d, 64);
         }
-        if (lane == 0) {
-            red_sb[wave] = sb;
-            red_sw[wave] = sw;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long tsb = 0, tsw = 0;
-            for (int w = 0; w < T / 64; ++w) {
-                tsb += red_sb[w];
-                tsw += red_sw[w];
+        unsigned long long tsb = sb, tsw = sw;
+        if constexpr (NT == 256) {
+            if (lane == 0) {
+                red_sb[wave] = sb;
+                red_sw[wave] = sw;
             }
+            __syncthreads();
+            if (tid == 0) {
+                tsb = 0;
+                tsw = 0;
+                for (int w = 0; w < T / 64; ++w) {
+                    tsb += red_sb[w];
+                    tsw += red_sw[w];
+                }
+            }
+        }
+        if (t == 0) {
             uint32_t c = crc_state;
-            for (uint64_t q = tail_lo; q < tail_hi; ++q) {
-                const uint32_t b = p0[q];
-                c = (c >> 8) ^ tab[(c ^ b) & 0xff];
-                tsb += b;
-                tsw += q * b;
+            uint32_t *tw = tailw[NT == 64 ? wave : 0];
+            // the bytes the lanes left over (fewer than 16, or a whole segment of fewer than 64): one
+            // aligned 16-byte load per piece, then bytes out of LDS -- a byte load from global memory
+            // per step would put a memory round trip into every step of this serial stretch
+            for (uint64_t q = tail_lo; q < tail_hi;) {
+                const uint32_t a2 = (uint32_t)((uintptr_t)(p0 + q) & 15u);
+                *(uint4 *)tw = *(const uint4 *)(p0 + q - a2);
+                const uint64_t left = tail_hi - q;
+                const uint32_t cnt = 16u - a2 < left ? 16u - a2 : (uint32_t)left;
+                for (uint32_t k = 0; k < cnt; ++k, ++q) {
+                    const uint32_t b = ((const volatile uint8_t *)tw)[a2 + k];
+                    c = (c >> 8) ^ tab[(c ^ b) & 0xff];
+                    tsb += b;
+                    tsw += q * b;
+                }
             }
             out_crc[sg] = c ^ 0xffffffffu;
             const unsigned long long nm = n % ADLER_MOD, bm = tsb % ADLER_MOD, wm = tsw % ADLER_MOD;
@@ -172,8 +201,20 @@ zgpu_checksum_kernel(const uint8_t *in, const uint64_t *seg_off, uint32_t n_segs
             const uint32_t s2 = (uint32_t)((nm + nm * bm + (ADLER_MOD - wm)) % ADLER_MOD);
             out_adler[sg] = (s2 << 16) | s1;
         }
-        __syncthreads();
+        if constexpr (NT == 256) __syncthreads();
     }
+}
+
+extern "C" __global__ void __launch_bounds__(ZGPU_CK_THREADS)
+zgpu_checksum_kernel(const uint8_t *in, const uint64_t *seg_off, uint32_t n_segs,
+                     const uint32_t *tables, uint32_t *out_crc, uint32_t *out_adler) {
+    checksum_segments<256>(in, seg_off, n_segs, tables, out_crc, out_adler);
+}
+// one wave per segment (tables with the extra advance block only: see build_tables)
+extern "C" __global__ void __launch_bounds__(ZGPU_CK_THREADS)
+zgpu_checksum_wave_kernel(const uint8_t *in, const uint64_t *seg_off, uint32_t n_segs,
+                          const uint32_t *tables, uint32_t *out_crc, uint32_t *out_adler) {
+    checksum_segments<64>(in, seg_off, n_segs, tables, out_crc, out_adler);
 }
 
 // ---- wide variant for large buffers -------------------------------------------

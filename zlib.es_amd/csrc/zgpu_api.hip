@@ -85,8 +85,9 @@ std::mutex g_mu;
 std::vector<DeviceState *> g_devs;
 std::vector<int> g_allowed;  // devices named by zgpu_init
 
+constexpr size_t kCkTabWords = 20 * 256 + 8;  // what zgpu_checksum_kernel reads; the wave variant's block follows
 void build_tables(std::vector<uint32_t> &t) {
-    t.assign(20 * 256 + 8, 0);
+    t.assign(kCkTabWords + 4 * 256, 0);
     for (uint32_t i = 0; i < 256; ++i) {
         uint32_t c = i;
         for (int k = 0; k < 8; ++k) c = (c & 1) ? (kPoly ^ (c >> 1)) : (c >> 1);
@@ -101,6 +102,10 @@ void build_tables(std::vector<uint32_t> &t) {
     for (int j = 0; j < 4; ++j)
         for (uint32_t v = 0; v < 256; ++v) t[(16 + j) * 256 + v] = h_gf_mul(v << (8 * j), adv);
     for (int lv = 0; lv < 8; ++lv) t[20 * 256 + lv] = h_xpow_bytes(16ull << lv);
+    // zgpu_checksum_wave_kernel: 64 lanes share a segment, a lane's remainder advances by 16 * 64 bytes
+    const uint32_t adv64 = h_xpow_bytes(16ull * 64);
+    for (int j = 0; j < 4; ++j)
+        for (uint32_t v = 0; v < 256; ++v) t[kCkTabWords + j * 256 + v] = h_gf_mul(v << (8 * j), adv64);
 }
 
 // tables of zgpu_checksum_wide_kernel, derived from the byte-sliced ones by linearity
@@ -1282,6 +1287,13 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             hipLaunchKernelGGL(zgpu_unit_fold_kernel, dim3(p->n_units / 256 + 1), dim3(256), 0, st, p->d_seg_off,
                                p->d_first_seg, p->b_seg_crc.as<uint32_t>(), p->b_seg_adler.as<uint32_t>(), p->n_units,
                                p->d_crc(), p->d_adler());
+        } else if (p->n_units >= 1024 && p->in_total / p->n_units <= (32u << 10)) {
+            // many small units: a wave each, four side by side in a workgroup (their time is the chain of
+            // round trips and the fold of the lanes' remainders, not their bytes)
+            const uint32_t wgs = (p->n_units + 3) / 4, gmax = (uint32_t)p->ds->cus * 6;
+            hipLaunchKernelGGL(zgpu_checksum_wave_kernel, dim3(wgs < gmax ? wgs : gmax), dim3(ZGPU_CK_THREADS), 0, st,
+                               (const uint8_t *)d_in, p->split ? p->d_unit_in_off : p->d_in_off, p->n_units,
+                               p->ds->d_tables, p->d_crc(), p->d_adler());
         } else {
             int grid = p->n_units < (uint32_t)p->ds->cus * 8 ? (int)p->n_units : p->ds->cus * 8;
             hipLaunchKernelGGL(zgpu_checksum_kernel, dim3(grid), dim3(ZGPU_CK_THREADS), 0, st,
@@ -1736,7 +1748,7 @@ int zgpu_noalloc_setup(void) {
     HIPCHK(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
     std::vector<uint32_t> t;
     build_tables(t);
-    HIPCHK(hipMemcpy(ptr + kNaTables, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ptr + kNaTables, t.data(), kCkTabWords * 4, hipMemcpyHostToDevice));  // the workgroup kernel's part
     g_na_ptr[dev] = ptr;
     return ZGPU_OK;
 }
