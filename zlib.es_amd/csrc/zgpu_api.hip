@@ -452,32 +452,39 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
         if (piece < (128u << 10)) piece = 128u << 10;
         if (piece > p->knobs.split) piece = p->knobs.split;
         // Cutting is not free (a piece links the 32 KiB before it again and ends with its own blocks: about
-        // 6 % on 256 KiB pieces), so it has to win on the clock: both ways are played through -- the units,
-        // or their pieces, handed in order to the CU that is free first, time taken as bytes -- and the units
-        // stay whole unless the pieces finish sooner.  (1024 chunks of 1 MiB on 256 CUs are four rounds of
-        // whole units; 600 such chunks are three rounds whole and 2.5 cut.)
+        // 8 % on 256 KiB pieces), so it has to win on the clock: both ways are played through -- the units,
+        // or their pieces, handed in order to the workgroup that is free first, time taken as bytes: one
+        // search workgroup per CU, then eight emit workgroups per CU at 0.3 of the search's time per byte --
+        // and the units stay whole unless the pieces finish sooner.  (1024 chunks of 1 MiB on 256 CUs are four
+        // rounds of whole units; 600 such chunks are three rounds whole and 2.5 cut; 256 units of 4 MiB are
+        // cut because whole they would keep 256 of the 2048 emit workgroups busy for 64 blocks each.)
         auto makespan = [&](bool cut) {
-            std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> free_at;
-            for (int c = 0; c < ds->cus; ++c) free_at.push(0);
-            uint64_t end = 0;
-            auto give = [&](uint64_t cost) {
-                const uint64_t t = free_at.top() + cost;
-                free_at.pop();
-                free_at.push(t);
-                if (t > end) end = t;
-            };
-            for (uint32_t i = 0; i < n_units; ++i) {
-                const uint64_t n = in_off[i + 1] - in_off[i];
-                if (n <= kHalfWindowMax) continue;
-                if (cut && n > 2 * piece) {
-                    for (uint64_t o = 0; o < n; o += piece) {
-                        const uint64_t len = n - o < piece ? n - o : piece;
-                        give(len + (o ? 8192 + len / 32 : 0));  // priming and framing of a piece
-                    }
-                } else
-                    give(n);
+            uint64_t total = 0;
+            for (int phase = 0; phase < 2; ++phase) {  // 0: search, 1: emit
+                std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> free_at;
+                const int workers = phase ? ds->cus * ZGPU_EMIT_WG_PER_CU : ds->cus;
+                for (int c = 0; c < workers; ++c) free_at.push(0);
+                uint64_t end = 0;
+                auto give = [&](uint64_t cost) {
+                    const uint64_t t = free_at.top() + cost;
+                    free_at.pop();
+                    free_at.push(t);
+                    if (t > end) end = t;
+                };
+                for (uint32_t i = 0; i < n_units; ++i) {
+                    const uint64_t n = in_off[i + 1] - in_off[i];
+                    if (n <= kHalfWindowMax) continue;
+                    if (cut && n > 2 * piece) {
+                        for (uint64_t o = 0; o < n; o += piece) {
+                            const uint64_t len = n - o < piece ? n - o : piece;
+                            give(phase ? len * 3 / 10 : len + (o ? 21000 : 0));  // priming and framing of a piece
+                        }
+                    } else
+                        give(phase ? n * 3 / 10 : n);
+                }
+                total += end;
             }
-            return end;
+            return total;
         };
         if (makespan(false) <= makespan(true)) piece = 0;
     }
