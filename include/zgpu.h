@@ -180,6 +180,16 @@ int zgpu_deflate_batch_begin(const uint8_t *in, const uint64_t *in_off, uint32_t
                              uint32_t flags, zgpu_job **job, uint64_t *out_total);
 int zgpu_deflate_batch_finish(zgpu_job *job, uint8_t *out, uint64_t out_cap, uint64_t *out_off,
                               uint32_t *crc32, uint32_t *adler32);
+/* zgpu_deflate_batch_finish for a caller that frames every unit itself: unit i's
+ * stream is placed gap[i] bytes behind the end of unit i-1's (behind the start
+ * of out for unit 0), so that the caller can write a header in front of each --
+ * what Zip#compress() does around every file (local file header, then the
+ * compressed bytes: src/zip.js:151-262) -- without copying the streams again.
+ * out_pos: n_units+1 positions in out (entry n_units: the end of the last
+ * stream); out_cap >= total + sum of gaps.  Releases the job like
+ * zgpu_deflate_batch_finish. */
+int zgpu_deflate_batch_finish_spaced(zgpu_job *job, uint8_t *out, uint64_t out_cap, const uint32_t *gap,
+                                     uint64_t *out_pos, uint32_t *crc32, uint32_t *adler32);
 void zgpu_job_release(zgpu_job *job);
 
 /* ---- RawDeflate, device-resident plan ------------------------------------

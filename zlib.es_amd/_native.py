@@ -20,6 +20,7 @@ SYMBOLS = [
     "zgpu_init", "zgpu_device_count", "zgpu_shutdown", "zgpu_host_devices", "zgpu_partition_units", "zgpu_strerror", "zgpu_last_hip_error", "zgpu_set_search", "zgpu_set_split",
     "zgpu_set_min_lazy", "zgpu_set_long_match",
     "zgpu_deflate_bound", "zgpu_deflate_batch", "zgpu_deflate_batch_begin", "zgpu_deflate_batch_finish",
+    "zgpu_deflate_batch_finish_spaced",
     "zgpu_job_release", "zgpu_plan_create", "zgpu_plan_destroy",
     "zgpu_plan_out_bound", "zgpu_plan_run", "zgpu_plan_out_off_device", "zgpu_plan_crc_device",
     "zgpu_plan_adler_device", "zgpu_plan_fetch", "zgpu_plan_kernel_ms", "zgpu_plan_phase_ms", "zgpu_checksum",
@@ -77,6 +78,8 @@ def lib():
     L.zgpu_deflate_batch_begin.argtypes = [vp, vp, u32, i32, i32, u32, C.POINTER(vp), C.POINTER(u64)]
     L.zgpu_deflate_batch_finish.restype = i32
     L.zgpu_deflate_batch_finish.argtypes = [vp, vp, u64, vp, vp, vp]
+    L.zgpu_deflate_batch_finish_spaced.restype = i32
+    L.zgpu_deflate_batch_finish_spaced.argtypes = [vp, vp, u64, vp, vp, vp, vp]
     L.zgpu_job_release.restype = None
     L.zgpu_job_release.argtypes = [vp]
     L.zgpu_plan_create.restype = i32

@@ -1621,6 +1621,61 @@ int zgpu_deflate_batch_finish(zgpu_job *j, uint8_t *out, uint64_t out_cap, uint6
     return rc;
 }
 
+int zgpu_deflate_batch_finish_spaced(zgpu_job *j, uint8_t *out, uint64_t out_cap, const uint32_t *gap,
+                                     uint64_t *out_pos, uint32_t *crc32, uint32_t *adler32) {
+    if (!j) return ZGPU_E_ARG;
+    int rc = ZGPU_OK;
+    const size_t n = j->n_units;
+    const uint64_t total = j->out_off[n];
+    uint64_t gaps = 0;
+    if (gap)
+        for (size_t i = 0; i < n; ++i) gaps += gap[i];
+    if (!gap || !out_pos || !out || (crc32 && j->crc.empty()) || (adler32 && j->adler.empty())) {
+        rc = ZGPU_E_ARG;
+    } else if (total + gaps > out_cap) {
+        rc = ZGPU_E_OUTCAP;
+    } else {
+        uint64_t run = 0;
+        for (size_t i = 0; i < n; ++i) {
+            run += gap[i];
+            out_pos[i] = j->out_off[i] + run;
+        }
+        out_pos[n] = total + run;
+        bool all_staged = true;
+        for (const zgpu_job::Dev &dv : j->devs) all_staged = all_staged && dv.staged;
+        // where unit i's bytes lie now: in the page-locked staging of its device, or -- results too large
+        // to stage -- in a contiguous host copy made first
+        std::unique_ptr<uint8_t[]> flat;
+        if (!all_staged && total) {
+            flat.reset(new (std::nothrow) uint8_t[total]);
+            rc = flat ? host_batch_copy_out(j, flat.get()) : ZGPU_E_NOMEM;
+        }
+        if (rc == ZGPU_OK && total) {
+            const int nth = total >= (64ull << 20) ? 4 : (total >= (4ull << 20) ? 2 : 1);
+            auto mover = [&](int part) {
+                for (size_t si = (size_t)part; si < j->subs.size(); si += (size_t)nth) {
+                    const SubBatch &sb = j->subs[si];
+                    const uint8_t *src = flat ? flat.get() + j->out_off[sb.first]
+                                              : (const uint8_t *)j->devs[sb.dev_index].h_res.p + sb.res_off;
+                    const uint64_t base = j->out_off[sb.first];
+                    for (uint32_t i = sb.first; i < sb.end; ++i)
+                        memcpy(out + out_pos[i], src + (j->out_off[i] - base), j->out_off[i + 1] - j->out_off[i]);
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < nth; ++t) th.emplace_back(mover, t);
+            mover(0);
+            for (auto &t : th) t.join();
+        }
+        if (rc == ZGPU_OK) {
+            if (crc32) memcpy(crc32, j->crc.data(), n * sizeof(uint32_t));
+            if (adler32) memcpy(adler32, j->adler.data(), n * sizeof(uint32_t));
+        }
+    }
+    zgpu_job_release(j);
+    return rc;
+}
+
 void zgpu_job_release(zgpu_job *j) {
     if (!j) return;
     int cur = 0;

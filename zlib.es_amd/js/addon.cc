@@ -21,6 +21,7 @@ typedef int (*fn_deflate_batch)(const uint8_t *, const uint64_t *, uint32_t, int
                                 uint64_t, uint64_t *, uint32_t *, uint32_t *);
 typedef int (*fn_batch_begin)(const uint8_t *, const uint64_t *, uint32_t, int, int, uint32_t, void **, uint64_t *);
 typedef int (*fn_batch_finish)(void *, uint8_t *, uint64_t, uint64_t *, uint32_t *, uint32_t *);
+typedef int (*fn_batch_finish_spaced)(void *, uint8_t *, uint64_t, const uint32_t *, uint64_t *, uint32_t *, uint32_t *);
 typedef int (*fn_checksum)(const uint8_t *, uint64_t, uint32_t *, uint32_t *);
 typedef uint64_t (*fn_bound)(uint64_t);
 typedef uint32_t (*fn_combine)(uint32_t, uint32_t, uint64_t);
@@ -33,6 +34,7 @@ struct Lib {
     fn_deflate_batch deflate_batch = nullptr;
     fn_batch_begin batch_begin = nullptr;
     fn_batch_finish batch_finish = nullptr;
+    fn_batch_finish_spaced batch_finish_spaced = nullptr;
     void (*job_release)(void *) = nullptr;
     fn_checksum checksum = nullptr;
     fn_bound bound = nullptr;
@@ -123,6 +125,7 @@ napi_value Init_(napi_env env, napi_callback_info info) {
     g.deflate_batch = (fn_deflate_batch)dlsym(h, "zgpu_deflate_batch");
     g.batch_begin = (fn_batch_begin)dlsym(h, "zgpu_deflate_batch_begin");
     g.batch_finish = (fn_batch_finish)dlsym(h, "zgpu_deflate_batch_finish");
+    g.batch_finish_spaced = (fn_batch_finish_spaced)dlsym(h, "zgpu_deflate_batch_finish_spaced");
     g.job_release = (void (*)(void *))dlsym(h, "zgpu_job_release");
     g.checksum = (fn_checksum)dlsym(h, "zgpu_checksum");
     g.bound = (fn_bound)dlsym(h, "zgpu_deflate_bound");
@@ -136,7 +139,7 @@ napi_value Init_(napi_env env, napi_callback_info info) {
     g.init = (int (*)(const int *, int))dlsym(h, "zgpu_init");
     g.device_count = (int (*)())dlsym(h, "zgpu_device_count");
     g.host_devices = (int (*)(int *, int))dlsym(h, "zgpu_host_devices");
-    if (!g.deflate_batch || !g.batch_begin || !g.batch_finish || !g.job_release || !g.checksum || !g.bound || !g.crc_combine || !g.adler_combine || !g.strerror_ ||
+    if (!g.deflate_batch || !g.batch_begin || !g.batch_finish || !g.batch_finish_spaced || !g.job_release || !g.checksum || !g.bound || !g.crc_combine || !g.adler_combine || !g.strerror_ ||
         !g.set_search || !g.set_min_lazy || !g.set_split || !g.set_long_match || !g.init || !g.device_count || !g.host_devices) {
         dlclose(h);
         napi_throw_error(env, nullptr, "libzgpu.so lacks an expected symbol");
@@ -179,8 +182,8 @@ bool get_u8(napi_env env, napi_value v, const uint8_t **data, size_t *len) {
 //   -> { outputs: Uint8Array[] (views into one ArrayBuffer), crc32: Uint32Array|null, adler32: Uint32Array|null }
 napi_value DeflateBatch(napi_env env, napi_callback_info info) {
     if (!need_lib(env)) return nullptr;
-    size_t argc = 6;
-    napi_value argv[6];
+    size_t argc = 8;
+    napi_value argv[8];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     if (argc < 6) {
         napi_throw_type_error(env, nullptr, "deflateBatch(inputs, ctype, lazy, flags, wantCrc, wantAdler)");
@@ -202,7 +205,30 @@ napi_value DeflateBatch(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_create_array_with_length(env, n, &outs));
     napi_value null_v;
     NAPI_OK(napi_get_null(env, &null_v));
-    napi_value crc_v = null_v, adler_v = null_v;
+    napi_value crc_v = null_v, adler_v = null_v, buffer_v = null_v;
+    // spaced mode (for callers that frame every unit themselves, like Zip#compress()): gaps[i] bytes are
+    // left free in front of unit i's stream and `tail` bytes behind the last; the result also carries the
+    // one ArrayBuffer (`buffer`) and the end of the last stream (`end`)
+    const uint32_t *gaps = nullptr;
+    double tail = 0;
+    if (argc >= 7) {
+        bool is_ta = false;
+        if (napi_is_typedarray(env, argv[6], &is_ta) == napi_ok && is_ta) {
+            napi_typedarray_type tt;
+            size_t gl = 0, goff = 0;
+            void *gp = nullptr;
+            napi_value gab;
+            NAPI_OK(napi_get_typedarray_info(env, argv[6], &tt, &gl, &gp, &gab, &goff));
+            if (tt != napi_uint32_array || gl != n) {
+                napi_throw_type_error(env, nullptr, "gaps: a Uint32Array with one entry per input");
+                return nullptr;
+            }
+            gaps = (const uint32_t *)gp;
+            if (argc >= 8) NAPI_OK(napi_get_value_double(env, argv[7], &tail));
+            if (tail < 0 || tail > 4294967295.0) tail = 0;
+        }
+    }
+    double end_pos = 0;
     if (n) {
         std::vector<uint64_t> in_off(n + 1, 0), out_off(n + 1, 0);
         std::vector<const uint8_t *> ptrs(n);
@@ -252,16 +278,36 @@ napi_value DeflateBatch(napi_env env, napi_callback_info info) {
             }
         } guard{job};
         flat.reset();
+        uint64_t room = total;
+        if (gaps) {
+            for (uint32_t i = 0; i < n; ++i) room += gaps[i];
+            room += (uint64_t)tail;
+        }
         void *ab_data = nullptr;
         napi_value ab;
-        if (napi_create_arraybuffer(env, total, &ab_data, &ab) != napi_ok) {
+        if (napi_create_arraybuffer(env, room, &ab_data, &ab) != napi_ok) {
             napi_throw_error(env, nullptr, "cannot allocate the output ArrayBuffer");
             return nullptr;
         }
         guard.job = nullptr;
-        rc = g.batch_finish(job, (uint8_t *)ab_data, total, out_off.data(), want_crc ? crc.data() : nullptr,
-                            want_adler ? adler.data() : nullptr);
+        if (gaps)
+            rc = g.batch_finish_spaced(job, (uint8_t *)ab_data, room, gaps, out_off.data(), want_crc ? crc.data() : nullptr,
+                                       want_adler ? adler.data() : nullptr);
+        else
+            rc = g.batch_finish(job, (uint8_t *)ab_data, total, out_off.data(), want_crc ? crc.data() : nullptr,
+                                want_adler ? adler.data() : nullptr);
         if (rc) return throw_zgpu(env, "zgpu_deflate_batch_finish", rc);
+        if (gaps) {
+            // positions of a spaced result: unit i's stream ends where the gap of unit i + 1 begins
+            buffer_v = ab;
+            end_pos = (double)out_off[n];
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint64_t stop = i + 1 < n ? out_off[i + 1] - gaps[i + 1] : out_off[n];
+                napi_value ta;
+                NAPI_OK(napi_create_typedarray(env, napi_uint8_array, stop - out_off[i], ab, out_off[i], &ta));
+                NAPI_OK(napi_set_element(env, outs, i, ta));
+            }
+        } else
         for (uint32_t i = 0; i < n; ++i) {
             napi_value ta;
             NAPI_OK(napi_create_typedarray(env, napi_uint8_array, out_off[i + 1] - out_off[i], ab, out_off[i], &ta));
@@ -280,6 +326,12 @@ napi_value DeflateBatch(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_set_named_property(env, result, "outputs", outs));
     NAPI_OK(napi_set_named_property(env, result, "crc32", crc_v));
     NAPI_OK(napi_set_named_property(env, result, "adler32", adler_v));
+    if (gaps) {
+        napi_value end_v;
+        NAPI_OK(napi_create_double(env, end_pos, &end_v));
+        NAPI_OK(napi_set_named_property(env, result, "buffer", buffer_v));
+        NAPI_OK(napi_set_named_property(env, result, "end", end_v));
+    }
     return result;
 }
 

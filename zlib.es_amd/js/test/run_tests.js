@@ -208,6 +208,31 @@ it('Zip: extra field is written to both headers', () => {
 	assert.ok(H.equal(files.plain, H.makeText(3000, 3)));
 });
 
+it('Zip: streams written in place give the archive the copying way gives', () => {
+	const date = new Date(2024, 0, 2, 3, 4, 6);
+	const build = (copy) => {
+		const zip = new Zlib.Zip({ comment: new Uint8Array(Buffer.from('archive comment')) });
+		const mt = new H.MT(5);
+		for (let f = 0; f < 200; ++f) {
+			const n = mt.next() % 40000;
+			zip.addFile(f % 5 === 4 ? H.makeRandomData(n, f) : H.makeText(n, f), {
+				filename: new Uint8Array(Buffer.from('dir/' + f + '.txt')), date,
+				extraField: f % 7 === 0 ? new Uint8Array([1, 2, 3, 4]) : undefined,
+				comment: f % 11 === 0 ? new Uint8Array(Buffer.from('c' + f)) : undefined,
+			});
+		}
+		Zlib.Zip.copyStreams = copy;
+		try {
+			return zip.compress();
+		} finally {
+			Zlib.Zip.copyStreams = false;
+		}
+	};
+	const inPlace = build(false), copied = build(true);
+	assert.ok(H.equal(inPlace, copied));
+	assert.strictEqual(Object.keys(unzip(inPlace)).length, 200);
+});
+
 // ---- batch API ----
 it('RawDeflate.compressBatch', () => {
 	const ins = [inputs.random.subarray(0, 1000), inputs.sequential, H.makeText(100000, 3), new Uint8Array(0), new Uint8Array([65])];

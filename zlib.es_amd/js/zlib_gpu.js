@@ -342,8 +342,40 @@ class Zip {
 			});
 		}
 	}
+	// The usual archive -- every file still to be compressed, all with the same deflate options, no
+	// password: one engine call that leaves room for each file's local header in front of its stream and
+	// for the central directory behind the last, so the compressed bytes are written once, in place.
+	// Returns the archive buffer with the streams in it, or null when the archive is not of that kind.
+	_compressInPlace() {
+		const files = this.files;
+		if (!files.length || this.password !== void 0 || Zip.copyStreams) return null;
+		let ct = -1, lazy = 0, tail = 22 + (this.comment ? this.comment.length : 0);
+		const gaps = new Uint32Array(files.length);
+		for (let i = 0; i < files.length; ++i) {
+			const f = files[i], opt = f.option;
+			if (f.compressed || opt.password !== void 0 || opt.compressionMethod !== Zip.CompressionMethod.DEFLATE) return null;
+			const d = opt.deflateOption || {};
+			const c = typeof d.compressionType === 'number' ? d.compressionType : 2;
+			if (c !== 1 && c !== 2) return null;
+			if (i === 0) {
+				ct = c;
+				lazy = d.lazy | 0;
+			} else if (c !== ct || (d.lazy | 0) !== lazy) return null;
+			const nameLen = opt.filename ? opt.filename.length : 0, extraLen = opt.extraField ? opt.extraField.length : 0;
+			gaps[i] = 30 + nameLen + extraLen;
+			tail += 46 + nameLen + extraLen + (opt.comment ? opt.comment.length : 0);
+		}
+		const r = addon.deflateBatch(files.map((f) => asU8(f.buffer)), ct, lazy, F_FINAL_EACH, true, false, gaps, tail);
+		files.forEach((f, i) => {
+			f.crc32 = r.crc32[i];
+			f.buffer = r.outputs[i];
+			f.compressed = true;
+		});
+		return new Uint8Array(r.buffer);
+	}
 	// src/zip.js:98-274
 	compress() {
+		const inPlace = this._compressInPlace();
 		this._compressPending();
 		const files = this.files;
 		let localFileSize = 0, centralDirectorySize = 0;
@@ -366,8 +398,14 @@ class Zip {
 			centralDirectorySize += 46 + filenameLength + extraLength + commentLength;
 		}
 		const endOfCentralDirectorySize = 22 + (this.comment ? this.comment.length : 0);
-		const output = new Uint8Array(localFileSize + centralDirectorySize + endOfCentralDirectorySize);
+		const archiveSize = localFileSize + centralDirectorySize + endOfCentralDirectorySize;
+		if (inPlace && inPlace.length !== archiveSize) throw new Error('archive size');
+		const output = inPlace || new Uint8Array(archiveSize);
 		let op1 = 0, op2 = localFileSize, op3 = op2 + centralDirectorySize;
+		const both = (v) => {
+			output[op1++] = output[op2++] = v & 0xff;
+		};
+		let now; // one clock reading serves the files without a date of their own (the reference reads it per file)
 		for (const file of files) {
 			const opt = file.option;
 			const filenameLength = opt.filename ? opt.filename.length : 0;
@@ -379,9 +417,6 @@ class Zip {
 			const needVersion = 20;
 			output[op2++] = needVersion & 0xff;
 			output[op2++] = opt.os || Zip.OperatingSystem.MSDOS;
-			const both = (v) => {
-				output[op1++] = output[op2++] = v & 0xff;
-			};
 			both(needVersion);
 			both(needVersion >> 8);
 			let flags = 0;
@@ -391,7 +426,7 @@ class Zip {
 			const compressionMethod = opt.compressionMethod;
 			both(compressionMethod);
 			both(compressionMethod >> 8);
-			const date = opt.date || new Date();
+			const date = opt.date || now || (now = new Date());
 			both(((date.getMinutes() & 0x7) << 5) | ((date.getSeconds() / 2) | 0));
 			both((date.getHours() << 3) | (date.getMinutes() >> 3));
 			both((((date.getMonth() + 1) & 0x7) << 5) | date.getDate());
@@ -428,7 +463,8 @@ class Zip {
 				output.set(opt.comment, op2);
 				op2 += commentLength;
 			}
-			output.set(file.buffer, op1);
+			if (!inPlace) output.set(file.buffer, op1);  // in place: the stream is already there
+			else if (file.buffer.byteOffset !== op1) throw new Error('stream position');
 			op1 += file.buffer.length;
 		}
 		for (let k = 0; k < 4; ++k) output[op3++] = Zip.CentralDirectorySignature[k];
@@ -471,6 +507,7 @@ class Zip {
 	}
 }
 Zip.CompressionMethod = { STORE: 0, DEFLATE: 8 };
+Zip.copyStreams = false; // true: Zip#compress() always copies the compressed streams into the archive (the reference's way; for tests)
 Zip.OperatingSystem = { MSDOS: 0, UNIX: 3, MACINTOSH: 7 };
 Zip.Flags = { ENCRYPT: 0x0001, DESCRIPTOR: 0x0008, UTF8: 0x0800 };
 Zip.FileHeaderSignature = [0x50, 0x4b, 0x01, 0x02];
