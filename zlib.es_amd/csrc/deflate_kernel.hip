@@ -780,12 +780,16 @@ __device__ __forceinline__ void search_units(const Params &P) {
             uint32_t *slot_entry = (uint32_t *)(scr + S_ENT);
             uint32_t *slot_tokb = (uint32_t *)(scr + S_TOKB);
             auto safe_bound = [&]() -> uint32_t {
-                uint32_t o[WG / 64];
-#pragma unroll
-                for (int w = 0; w < WG / 64; ++w) o[w] = lds_ld(&misc[M_OLDEST + w]);
-                uint32_t m = o[0];
-#pragma unroll
-                for (int w = 1; w < WG / 64; ++w) m = o[w] < m ? o[w] : m;
+                // four words at a time (this runs on whatever lanes the caller has active, often one; all the
+                // words in registers at once would count against the variants that run at 64 VGPRs)
+                uint32_t m = 0xffffffffu;
+#pragma unroll 1
+                for (int w = 0; w < WG / 64; w += 4) {
+                    const uint32_t a = lds_ld(&misc[M_OLDEST + w]), b = lds_ld(&misc[M_OLDEST + w + 1]),
+                                   c = lds_ld(&misc[M_OLDEST + w + 2]), d = lds_ld(&misc[M_OLDEST + w + 3]);
+                    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d, x = ab < cd ? ab : cd;
+                    m = x < m ? x : m;
+                }
                 return m + NSLOT_E;
             };
             // The frontier is one lane's serial work and every wave's start waits on it (LAG), so
