@@ -146,3 +146,72 @@ def test_knobs_are_read_when_a_plan_is_created(z):
         assert run(deep_plan) < run(fast_plan)  # the plan kept what it read, whatever was set later
     finally:
         N.set_long_match()
+
+
+def test_batch_split_over_named_devices_on_the_one_gpu(z):
+    """zgpu_init may name a device more than once: the batch is then split by bytes over two 'devices' that
+    are the same GPU, so the partition, the per-device host threads and the concatenation of the multi-device
+    path run for real on a one-GPU box.  The bytes must be those of the single-device call."""
+    N = z._native
+    L = N.lib()
+    units = [zo.gen({"gen": ("text", "rndseq", "rnd", "runs")[i % 4], "n": 1 << 20, "seed": 40 + i}) for i in range(300)]  # 300 MiB
+    flat = np.concatenate(units)
+    n = len(units)
+    off = (np.arange(n + 1, dtype=np.uint64) << np.uint64(20))
+    cap = sum(N.deflate_bound(u.size) + 64 for u in units)
+
+    def run(flags):
+        out = np.empty(cap, dtype=np.uint8)
+        out_off = np.zeros(n + 1, dtype=np.uint64)
+        crc = np.zeros(n, dtype=np.uint32)
+        rc = L.zgpu_deflate_batch(flat.ctypes.data, off.ctypes.data, n, 2, 0, flags, out.ctypes.data, cap,
+                                  out_off.ctypes.data, crc.ctypes.data, None)
+        assert rc == 0
+        return out[:int(out_off[n])].tobytes(), out_off.tolist(), crc.tolist()
+
+    single = {f: run(f) for f in (N.F_FINAL_EACH, N.F_SYNC_ALIGN | N.F_FINAL_LAST | N.F_PRIME_WINDOW)}
+    ids = (C.c_int32 * 2)(0, 0)
+    assert L.zgpu_init(ids, 2) == 0
+    try:
+        got = (C.c_int32 * 8)()
+        assert L.zgpu_host_devices(got, 8) == 2
+        for f, ref in single.items():
+            twice = run(f)
+            assert twice[1] == ref[1] and twice[2] == ref[2], f
+            assert twice[0] == ref[0], f
+    finally:
+        assert L.zgpu_init(None, 0) == 0
+    # the chunked stream of the second flag set is one valid stream
+    body = single[N.F_SYNC_ALIGN | N.F_FINAL_LAST | N.F_PRIME_WINDOW][0]
+    assert zo.inflate_raw(body, flat.size) == flat.tobytes()
+
+
+def test_spaced_finish_leaves_room_in_front_of_every_stream(z):
+    N = z._native
+    L = N.lib()
+    units = _mixed_units(400, 9) + [np.zeros(0, dtype=np.uint8)]
+    flat = np.concatenate(units)
+    n = len(units)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([u.size for u in units])
+    job, total = C.c_void_p(None), C.c_uint64(0)
+    assert L.zgpu_deflate_batch_begin(flat.ctypes.data, off.ctypes.data, n, 2, 0, N.F_FINAL_EACH | N.F_WANT_CRC,
+                                      C.byref(job), C.byref(total)) == 0
+    gaps = (np.arange(n, dtype=np.uint32) % 7) * 5 + 30
+    room = int(total.value + gaps.sum()) + 100
+    out = np.full(room, 0xA5, dtype=np.uint8)
+    pos = np.zeros(n + 1, dtype=np.uint64)
+    crc = np.zeros(n, dtype=np.uint32)
+    assert L.zgpu_deflate_batch_finish_spaced(job, out.ctypes.data, room, gaps.ctypes.data, pos.ctypes.data,
+                                              crc.ctypes.data, None) == 0
+    assert int(pos[n]) == int(total.value + gaps.sum())
+    assert np.all(out[int(pos[n]):] == 0xA5)
+    prev_end = 0
+    for i, u in enumerate(units):
+        start = int(pos[i])
+        assert start == prev_end + int(gaps[i])
+        assert np.all(out[prev_end:start] == 0xA5), "a gap was written into"
+        end = int(pos[i + 1]) - int(gaps[i + 1]) if i + 1 < n else int(pos[n])
+        assert zo.inflate_raw(out[start:end].tobytes(), u.size) == u.tobytes(), i
+        assert int(crc[i]) == zo.crc32(u)
+        prev_end = end
