@@ -1253,10 +1253,48 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             unsigned long long sm = starts();
                             bool go = ((sm >> lane) & 1ull) && last != 0xffffu;
                             if (__ballot(go)) {
+                                // A match longer than the best one, at whatever distance, repeats the four
+                                // bytes that straddle the best one's end (three inside, one after) at that
+                                // distance: the candidate is on the chain of the position t that starts those
+                                // four bytes.  When t's link leads to no earlier occurrence within reach,
+                                // nothing longer exists and the walk ends (or never starts): a match that
+                                // ends because the data goes on differently than anywhere before -- the
+                                // usual case where runs and records of different lengths follow each other
+                                // -- then costs two round trips instead of the whole chain.  (A hash
+                                // collision in front of a real occurrence ends a walk too early; that costs
+                                // size, never correctness.)  t's link exists once t's item is linked: the
+                                // same horizon as the probe-ahead step below, waited for the same way.
+                                uint32_t horizon = 0xffffffffu;
+                                if constexpr (AHEAD == 0) {
+                                    constexpr uint32_t FAN_ITEMS = WG / 64 < 5 ? WG / 64 : 5;
+                                    const uint32_t hz = k + FAN_ITEMS < blk_end ? k + FAN_ITEMS : blk_end;
+                                    lds_wait_ge(&misc[M_LINKED], hz);
+                                    horizon = hz << 6;
+                                }
+                                bool chk = go;
                                 uint32_t tb = ring[(pi + blen) & (RING - 1)];
                                 uint32_t seq = 0;
                                 unsigned long long improved = 0;
                                 for (int budget = P.deep; budget > 0; --budget) {
+                                    if (__ballot(chk)) {
+                                        if (chk) {
+                                            const uint32_t t = p + blen - 3u;
+                                            if (t + 4u <= n && t < horizon) {
+                                                const uint32_t c2 = prevt[t & WMASK];
+                                                const uint32_t d = (t - c2) & 0xffffu;
+                                                bool ok = d >= 1u && d <= limit;
+                                                if (ok) {
+                                                    const uint32_t s4 = t - d;
+                                                    const uint32_t *wt = (const uint32_t *)(ring + (t & (RING - 1) & ~3u));
+                                                    const uint32_t *ws = (const uint32_t *)(ring + (s4 & (RING - 1) & ~3u));
+                                                    ok = __builtin_amdgcn_alignbyte(wt[1], wt[0], t & 3u) ==
+                                                         __builtin_amdgcn_alignbyte(ws[1], ws[0], s4 & 3u);
+                                                }
+                                                go = go && ok;
+                                            }
+                                            chk = false;
+                                        }
+                                    }
                                     const uint32_t dist = (p - c) & 0xffffu;
                                     if (dist <= last || dist > limit) go = false;
                                     // a chain that runs through consecutive positions is a run of one
@@ -1283,6 +1321,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                                             best_dist = d;
                                             tb = ring[(pi + blen) & (RING - 1)];
                                             if (len >= maxlen) go = false;
+                                            chk = go;
                                             improved |= 1ull;
                                         }
                                     }
