@@ -252,9 +252,14 @@ def make_workload(ctx, workload, short):
         lens = torch.from_numpy(sizes[order]).to(dev)
         new_off = np.zeros(nf + 1, dtype=np.uint64)
         new_off[1:] = np.cumsum(sizes[order].astype(np.uint64))
-        seg = torch.repeat_interleave(torch.arange(nf, device=dev), lens)
-        pos = torch.arange(int(new_off[-1]), device=dev) - torch.from_numpy(new_off[:-1].astype(np.int64)).to(dev)[seg]
-        data = data[starts[seg] + pos]
+        packed = torch.empty(int(new_off[-1]), dtype=torch.uint8, device=dev)
+        for lo in range(0, nf, 32768):  # a slice of the files at a time: the index tensors are 8 bytes per byte moved
+            hi = min(nf, lo + 32768)
+            b0, b1 = int(new_off[lo]), int(new_off[hi])
+            seg = torch.repeat_interleave(torch.arange(hi - lo, device=dev), lens[lo:hi])
+            first = torch.from_numpy((new_off[lo:hi] - new_off[lo]).astype(np.int64)).to(dev)
+            packed[b0:b1] = data[starts[lo:hi][seg] + (torch.arange(b1 - b0, device=dev) - first[seg])]
+        data = packed
         desc = ("Zip.compress() batch: %d files of 1-%d B (uniform, mean %.1f KiB) of mixed text/binary per GPU, "
                 "half FIXED half DYNAMIC, CRC-32 per file" % (nf, mx, float(new_off[-1]) / nf / 1024))
         return data, [(new_off[: nfx + 1].copy(), 1, N.F_FINAL_EACH | N.F_WANT_CRC, "FIXED files"),
@@ -282,6 +287,7 @@ def bench_deflate(ctx, workload, short=False):
     barrier, red_dev = ctx["barrier"], ctx["red_dev"]
     steps, warmup = (2, 1) if short else (args.steps, args.warmup)
     data, groups, desc, cfg = make_workload(ctx, workload, short)
+    torch.cuda.empty_cache()  # the generator's temporaries go back to the device before the library allocates
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     plans, outs = [], []
     for off, ctype, flags, _ in groups:
