@@ -55,10 +55,14 @@ def test_random_batches(seed):
     adl_ref = [zo.adler32(d) for d in datas[:50]]
     try:
         # chunked: 1 = units are chunks of one stream, 2 = and each may match into the 32 KiB before it
-        for ctype, lazy, chain, nice, chunked in [(2, 0, 8, 32, 0), (1, 0, 8, 258, 0), (2, 16, 3, 32, 0),
-                                                  (2, 0, 32, 258, 1), (1, 7, 1, 8, 1), (2, 0, 8, 32, 2),
-                                                  (1, 3, 5, 40, 2)]:
+        # the last two settings add the long-match steps (deep walk 128 / 1024, two probe-ahead fans):
+        # units of every size class wait for the links of the items ahead of them there
+        for ctype, lazy, chain, nice, chunked, deep, fan in [
+                (2, 0, 8, 32, 0, 0, 1), (1, 0, 8, 258, 0, 0, 1), (2, 16, 3, 32, 0, 0, 1), (2, 0, 32, 258, 1, 0, 1),
+                (1, 7, 1, 8, 1, 0, 1), (2, 0, 8, 32, 2, 0, 1), (1, 3, 5, 40, 2, 0, 1), (2, 0, 8, 32, 0, 128, 2),
+                (1, 0, 4, 32, 2, 1024, 2)]:
             z.set_search(chain, nice)
+            N.set_long_match(deep, fan)
             flags = (N.F_SYNC_ALIGN | N.F_FINAL_LAST) if chunked else N.F_FINAL_EACH
             if chunked == 2:
                 flags |= N.F_PRIME_WINDOW
@@ -70,13 +74,14 @@ def test_random_batches(seed):
             st = gv.verify(d_comp, torch.from_numpy(co).cuda(), d_orig, d_ooff, final_each=not chunked,
                            primed=chunked == 2)
             bad = [(i, gv.STATUS[int(s)], datas[i].size) for i, s in enumerate(st.tolist()) if s]
-            assert not bad, (ctype, lazy, chain, nice, chunked, bad[:5])
+            assert not bad, (ctype, lazy, chain, nice, chunked, deep, fan, bad[:5])
             if chunked:
                 stream = b"".join(outs)
                 assert zo.inflate_raw(stream, flat.size) == flat.tobytes()
             assert all(len(o) <= z.deflate_bound(len(d)) for o, d in zip(outs, origs))
     finally:
         z.set_search()
+        N.set_long_match()
 
 
 def _skewed_unit(rng):
