@@ -15,6 +15,7 @@ where the reference emits an invalid or odd one):
   * ``lazy`` > 0 never emits the overlapping tail tokens of
     src/rawdeflate.js:329.
 """
+import random as _random
 import time
 
 import numpy as np
@@ -324,6 +325,47 @@ class Zip:
     def deflateWithOption(self, input, opt_params):
         return RawDeflate(input, opt_params.get("deflateOption")).compress()
 
+    # ---- ZipCrypto (src/zip.js:287-318): key[0..2] are 32-bit words ----
+    random = staticmethod(_random.random)  # the reference draws the header bytes from Math.random()
+
+    @staticmethod
+    def getByte(key):
+        tmp = (key[2] & 0xFFFF) | 2
+        return ((tmp * (tmp ^ 1)) >> 8) & 0xFF
+
+    def encode(self, key, n):
+        tmp = self.getByte(key)
+        self.updateKeys(key, n)
+        return tmp ^ n
+
+    @staticmethod
+    def updateKeys(key, n):
+        key[0] = CRC32.single(key[0], n)
+        key[1] = ((key[1] + (key[0] & 0xFF)) * 134775813 + 1) & 0xFFFFFFFF  # 20173 * 6681, :307
+        key[2] = CRC32.single(key[2], key[1] >> 24)
+
+    def createEncryptionKey(self, password):
+        key = [305419896, 591751049, 878082192]
+        for b in bytes(bytearray(int(x) & 0xFF for x in password)):
+            self.updateKeys(key, b)
+        return key
+
+    def _encode_many(self, key, data):
+        """encode() over a buffer with the key words in locals (the cipher is byte-serial: every
+        byte's key depends on the plaintext before it)"""
+        CRC32.single(0, 0)  # builds the table
+        t = CRC32._table
+        k0, k1, k2 = key
+        out = bytearray(data.size)
+        for j, n in enumerate(data.tobytes()):
+            tmp = (k2 & 0xFFFF) | 2
+            out[j] = (((tmp * (tmp ^ 1)) >> 8) & 0xFF) ^ n
+            k0 = t[(k0 ^ n) & 0xFF] ^ (k0 >> 8)
+            k1 = ((k1 + (k0 & 0xFF)) * 134775813 + 1) & 0xFFFFFFFF
+            k2 = t[(k2 ^ (k1 >> 24)) & 0xFF] ^ (k2 >> 8)
+        key[0], key[1], key[2] = k0, k1, k2
+        return np.frombuffer(bytes(out), dtype=np.uint8)
+
     def _compress_pending(self):
         """The batched form of the reference's first loop (:119-137)."""
         pending = [f for f in self.files if not f["compressed"]]
@@ -352,10 +394,21 @@ class Zip:
         self._compress_pending()
         files = self.files
         local_size = central_size = 0
-        for f in files:
+        for i, f in enumerate(files):
             opt = f["option"]
             if opt.get("password") is not None or self.password is not None:
-                raise NotImplementedError("ZipCrypto (src/zip.js:138-147,287-318) stays outside this engine")
+                # traditional PKZIP encryption, host arithmetic as in the reference (src/zip.js:138-147):
+                # twelve header bytes, then the data, through a byte-serial stream cipher.  The reference
+                # fills the header from Math.random() and tests the FILE index against 11 where the
+                # format puts a CRC byte into header byte 11; mirrored as it is (its own Unzip does not
+                # look at that byte).
+                key = self.createEncryptionKey(opt.get("password") or self.password)
+                plain = f["buffer"]
+                enc = np.empty(plain.size + 12, dtype=np.uint8)
+                for j in range(12):
+                    enc[j] = self.encode(key, (f["crc32"] & 0xFF) if i == 11 else int(self.random() * 256))
+                enc[12:] = self._encode_many(key, plain)
+                f["buffer"] = enc
             fl = len(opt["filename"]) if opt.get("filename") else 0
             cl = len(opt["comment"]) if opt.get("comment") else 0
             xl = len(opt["extraField"]) if opt.get("extraField") else 0
@@ -387,7 +440,8 @@ class Zip:
                 Y, Mo, D, h, mi, s = date.tm_year, date.tm_mon, date.tm_mday, date.tm_hour, date.tm_min, date.tm_sec
             crc, size, plain = f["crc32"], f["buffer"].size, f["size"]
             method = opt["compressionMethod"]
-            common = [need & 0xFF, (need >> 8) & 0xFF, 0, 0, method & 0xFF, (method >> 8) & 0xFF,
+            flags = Zip.Flags.ENCRYPT if (opt.get("password") or self.password) else 0  # :177-180
+            common = [need & 0xFF, (need >> 8) & 0xFF, flags & 0xFF, (flags >> 8) & 0xFF, method & 0xFF, (method >> 8) & 0xFF,
                       (((mi & 0x7) << 5) | (s // 2)) & 0xFF, ((h << 3) | (mi >> 3)) & 0xFF,
                       ((((Mo) & 0x7) << 5) | D) & 0xFF, ((((Y - 1980) & 0x7F) << 1) | (Mo >> 3)) & 0xFF,
                       crc & 0xFF, (crc >> 8) & 0xFF, (crc >> 16) & 0xFF, (crc >> 24) & 0xFF,
