@@ -55,6 +55,12 @@ def _js_streams(add):
                 f.write(bytes(d))
             for kind in ("raw", "zlib", "gzip"):
                 jobs.append({"file": path, "kind": kind, "spec": spec, "n": int(d.size), "sha256": sha(d)})
+        # one archive of the first two inputs under a password, through the shim's Zip
+        pw = list(b"hogefugapiyo")
+        jobs.append({"kind": "zip", "password": pw, "files": [os.path.join(tmp, "in0.bin"), os.path.join(tmp, "in1.bin")],
+                     "names": ["js0.bin", "js1.bin"],
+                     "entries": [{"name": "js%d.bin" % i, "n": int(zo.gen(JS_SPECS[i]).size), "sha256": sha(zo.gen(JS_SPECS[i]))}
+                                 for i in range(2)]})
         with open(os.path.join(tmp, "jobs.json"), "w") as f:
             json.dump(jobs, f)
         r = subprocess.run([node, os.path.join(JS, "test", "make_streams.js"), os.path.join(tmp, "jobs.json")],
@@ -63,6 +69,9 @@ def _js_streams(add):
             raise RuntimeError("make_streams.js failed: " + r.stdout[-2000:] + r.stderr[-2000:])
         outs = json.loads(r.stdout.strip().splitlines()[-1])
         for job, o in zip(jobs, outs):
+            if job["kind"] == "zip":
+                add({"kind": "zip", "via": "js", "password": job["password"], "entries": job["entries"], "b64": o})
+                continue
             add({"kind": job["kind"], "via": "js", "spec": job["spec"], "ctype": 2, "lazy": 0, "n": job["n"],
                  "sha256": job["sha256"], "b64": o})
 
@@ -133,5 +142,29 @@ def make_streams():
         zp.addFile(d, opt)
         entries.append({"name": name, "n": int(d.size), "sha256": sha(d)})
     add({"kind": "zip", "entries": entries, "b64": b64(zp.compress())})
+    # an archive under a password (traditional PKZIP encryption on the host, src/zip.js:138-147; the twelve
+    # header bytes per entry come from a pinned generator so that the archive can be regenerated)
+    st = [20121006]
+
+    def rnd():
+        st[0] = st[0] * 48271 % 2147483647
+        return st[0] / 2147483647
+    pw = list(b"hogefugapiyo")
+    zp = z.Zip()
+    zp.random = rnd
+    zp.setPassword(pw)
+    entries = []
+    for i, (spec, ct) in enumerate([({"gen": "text", "n": 20000, "seed": 21}, 2), ({"gen": "rndseq", "n": 9000, "seed": 22}, 1),
+                                    ({"gen": "rnd", "n": 500, "seed": 23}, 0)]):
+        d = zo.gen(spec)
+        name = "secret%d.bin" % i
+        opt = {"filename": list(name.encode()), "date": (2024, 1, 2, 3, 4, 6)}
+        if ct:
+            opt["deflateOption"] = {"compressionType": ct}
+        else:
+            opt["compressionMethod"] = 0
+        zp.addFile(d, opt)
+        entries.append({"name": name, "n": int(d.size), "sha256": sha(d)})
+    add({"kind": "zip", "password": pw, "entries": entries, "b64": b64(zp.compress())})
     _js_streams(add)
     return out

@@ -55,7 +55,8 @@ const sha = (u8) => crypto.createHash('sha256').update(Buffer.from(u8)).digest('
 				const out = new Gunzip(comp).decompress(); // checks CRC-32 and ISIZE
 				if (out.length !== s.n || sha(out) !== s.sha256) throw new Error('content differs: ' + out.length + ' bytes');
 			} else if (s.kind === 'zip') {
-				const uz = new Unzip(comp, { verify: true });
+				// an archive made under a password is decrypted by the reference's own Unzip (src/unzip.js:112-119)
+				const uz = new Unzip(comp, s.password ? { verify: true, password: new Uint8Array(s.password) } : { verify: true });
 				const names = uz.getFilenames();
 				if (names.length !== s.entries.length) throw new Error('entries: ' + names.join(','));
 				for (const e of s.entries) {

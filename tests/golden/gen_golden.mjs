@@ -274,6 +274,45 @@ out.zip = [];
 	out.zip.push({ files, date: [2013, 5, 17, 10, 31, 44], comment: 'archive', out: record(o, true) });
 }
 
+// ---- 7. ZipCrypto (src/zip.js:138-147,287-318): the cipher alone, and an archive of STORE entries under a
+// password with Math.random pinned (thirteen files: the header loop tests the file index against 11) ----
+out.zipcrypto = [];
+{
+	const z = new Zip();
+	for (const [pw, spec] of [
+		[[0, 1, 2, 3, 4, 5, 6, 7, 8, 9], { gen: 'seq', n: 300 }],
+		[Array.from(Buffer.from('hogefugapiyo')), { gen: 'rnd', n: 1000, seed: 7 }],
+	]) {
+		const key = z.createEncryptionKey(pw);
+		const keyAfterPassword = Array.from(key);
+		const plain = make(spec);
+		const enc = new Uint8Array(plain.length);
+		for (let i = 0; i < plain.length; ++i) enc[i] = z.encode(key, plain[i]);
+		out.zipcrypto.push({ password: pw, spec, key_after_password: keyAfterPassword, key_after: Array.from(key), out: record(enc, true) });
+	}
+	const realRandom = Math.random;
+	let st = 12345;
+	Math.random = () => {
+		st = (st * 48271) % 2147483647;
+		return st / 2147483647;
+	};
+	const date = new Date(2013, 4, 17, 10, 31, 44);
+	const enc = (s) => new Uint8Array(Buffer.from(s));
+	const zip = new Zip();
+	const files = [];
+	for (let i = 0; i < 13; ++i) {
+		const spec = { gen: 'rnd', n: 20 + 7 * i, seed: 100 + i };
+		const o = { filename: enc('f' + i + '.bin'), compressionMethod: 0, date };
+		if (i === 5) o.password = [9, 8, 7];
+		zip.addFile(make(spec), o);
+		files.push({ name: 'f' + i + '.bin', spec, password: i === 5 ? [9, 8, 7] : null });
+	}
+	zip.setPassword([0, 1, 2, 3, 4, 5, 6, 7, 8, 9]);
+	const o = zip.compress();
+	Math.random = realRandom;
+	out.zipcrypto_archive = { files, password: [0, 1, 2, 3, 4, 5, 6, 7, 8, 9], date: [2013, 5, 17, 10, 31, 44], random: 'st = st * 48271 % 2147483647 from 12345; st / 2147483647', out: record(o, true) };
+}
+
 fs.writeFileSync(path.join(here, 'golden.json'), JSON.stringify(out));
 fs.rmSync ? fs.rmSync(tmp, { recursive: true, force: true }) : fs.rmdirSync(tmp, { recursive: true });
 console.log('wrote golden.json:', out.cases.length, 'cases,', out.lazy.length, 'lazy,', out.fuzz.length, 'fuzz,', out.lengths.length, 'length tables');

@@ -158,3 +158,64 @@ def test_gzip_chunked_single_member(z):
     assert zo.gunzip(gzb, data.size) == data.tobytes()  # CRC-32 (by combine) and ISIZE verified
     import gzip as pygzip
     assert pygzip.decompress(gzb) == data.tobytes()
+
+
+def _lcg():
+    st = [12345]
+
+    def rnd():  # the generator tests/golden/gen_golden.mjs pins Math.random to
+        st[0] = st[0] * 48271 % 2147483647
+        return st[0] / 2147483647
+    return rnd
+
+
+def _read_encrypted(archive, passwords):
+    """{name: plain bytes} of an archive whose entries are encrypted; the twelve header bytes are
+    dropped unchecked, as the reference's Unzip does (src/unzip.js:113-117)."""
+    out = {}
+    zf = zipfile.ZipFile(io.BytesIO(archive))
+    for info in zf.infolist():
+        assert info.flag_bits & 1
+        o = info.header_offset
+        nlen, xlen = int.from_bytes(archive[o + 26:o + 28], "little"), int.from_bytes(archive[o + 28:o + 30], "little")
+        body = archive[o + 30 + nlen + xlen:o + 30 + nlen + xlen + info.compress_size]
+        dec = zipfile._ZipDecrypter(bytes(passwords[info.filename]))(body)[12:]
+        plain = zo.inflate_raw(dec, info.file_size) if info.compress_type == 8 else dec
+        assert zo.crc32(np.frombuffer(plain, dtype=np.uint8)) == info.CRC
+        out[info.filename] = plain
+    return out
+
+
+def test_zip_with_password_equals_the_reference_archive(z, golden):
+    # STORE entries under a password, header bytes from the same pinned generator: the archive is the
+    # reference's byte for byte (src/zip.js:138-147,177-180, incl. the file-index test at :144)
+    g = golden["zipcrypto_archive"]
+    zp = z.Zip()
+    zp.random = _lcg()
+    for f in g["files"]:
+        opt = {"filename": f["name"].encode(), "compressionMethod": 0, "date": tuple(g["date"])}
+        if f["password"] is not None:
+            opt["password"] = f["password"]
+        zp.addFile(zo.gen(f["spec"]), opt)
+    zp.setPassword(g["password"])
+    assert bytes(zp.compress()).hex() == g["out"]["hex"]
+
+
+def test_zip_compress_with_password(z):
+    # test/browser.es/zip-test.js:83-150: one password for the archive, then one per file
+    datas = {"hogehoge": zo.gen({"gen": "text", "n": 30000, "seed": 1}), "fugafuga": zo.gen({"gen": "rndseq", "n": 9000, "seed": 2}),
+             "piyopiyo": zo.gen({"gen": "rnd", "n": 700, "seed": 3})}
+    pw = list(range(10))
+    zp = z.Zip()
+    zp.setPassword(pw)
+    for name, d in datas.items():
+        zp.addFile(d, {"filename": name.encode(), "date": (2020, 1, 2, 3, 4, 6)})
+    got = _read_encrypted(bytes(zp.compress()), {name: pw for name in datas})
+    assert got == {name: d.tobytes() for name, d in datas.items()}
+    each = {name: [i + 1, 7, len(name)] for i, name in enumerate(datas)}
+    zp = z.Zip()
+    for name, d in datas.items():
+        zp.addFile(d, {"filename": name.encode(), "password": each[name], "date": (2020, 1, 2, 3, 4, 6),
+                       "deflateOption": {"compressionType": 1}})
+    got = _read_encrypted(bytes(zp.compress()), each)
+    assert got == {name: d.tobytes() for name, d in datas.items()}

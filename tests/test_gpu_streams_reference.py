@@ -29,12 +29,26 @@ def test_fixture_covers_the_containers():
     kinds = {}
     for s in _streams():
         kinds[s["kind"]] = kinds.get(s["kind"], 0) + 1
-    assert kinds["raw"] >= 20 and kinds["zlib"] >= 10 and kinds["gzip"] >= 10 and kinds["zip"] >= 1
+    assert kinds["raw"] >= 20 and kinds["zlib"] >= 10 and kinds["gzip"] >= 10 and kinds["zip"] >= 3  # one plain, two under a password (Python mirror, JS shim)
 
 
 def test_gpu_streams_decode_with_the_oracle():
     for s in _streams():
         comp = base64.b64decode(s["b64"])
+        if s["kind"] == "zip" and s.get("password"):
+            # encrypted entries: the cipher undone with CPython's decrypter, the twelve header bytes dropped
+            # unchecked (the reference fills all twelve from Math.random, src/zip.js:144), then the strict inflater
+            with zipfile.ZipFile(io.BytesIO(comp)) as zf:
+                infos = {i.filename: i for i in zf.infolist()}
+            for e in s["entries"]:
+                i = infos[e["name"]]
+                assert i.flag_bits & 1
+                o = i.header_offset
+                skip = 30 + int.from_bytes(comp[o + 26:o + 28], "little") + int.from_bytes(comp[o + 28:o + 30], "little")
+                body = zipfile._ZipDecrypter(bytes(s["password"]))(comp[o + skip:o + skip + i.compress_size])[12:]
+                plain = zo.inflate_raw(body, i.file_size) if i.compress_type == 8 else body
+                assert len(plain) == e["n"] and hashlib.sha256(plain).hexdigest() == e["sha256"]
+            continue
         if s["kind"] == "zip":
             with zipfile.ZipFile(io.BytesIO(comp)) as zf:
                 assert zf.testzip() is None

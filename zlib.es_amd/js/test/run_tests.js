@@ -114,7 +114,31 @@ it('Gzip with filename, comment and header crc', () => {
 });
 
 // ---- zip-test.js:17-152 (STORE / DEFLATE entries; central directory parsed here) ----
-function unzip(z) {
+// traditional PKZIP decryption (the stream cipher of src/unzip.js:113-117, written out for the test):
+// the twelve header bytes are dropped unchecked, as the reference's Unzip drops them
+function zipDecrypt(body, password) {
+	const key = [305419896, 591751049, 878082192];
+	const crcTab = new Uint32Array(256);
+	for (let i = 0; i < 256; ++i) {
+		let c = i;
+		for (let k = 0; k < 8; ++k) c = c & 1 ? 0xedb88320 ^ (c >>> 1) : c >>> 1;
+		crcTab[i] = c >>> 0;
+	}
+	const upd = (n) => {
+		key[0] = (crcTab[(key[0] ^ n) & 0xff] ^ (key[0] >>> 8)) >>> 0;
+		key[1] = (Math.imul(key[1] + (key[0] & 0xff), 134775813) + 1) >>> 0;
+		key[2] = (crcTab[(key[2] ^ (key[1] >>> 24)) & 0xff] ^ (key[2] >>> 8)) >>> 0;
+	};
+	for (const b of password) upd(b & 0xff);
+	const out = new Uint8Array(body.length);
+	for (let i = 0; i < body.length; ++i) {
+		const t = (key[2] & 0xffff) | 2;
+		out[i] = body[i] ^ ((Math.imul(t, t ^ 1) >>> 8) & 0xff);
+		upd(out[i]);
+	}
+	return out.subarray(12);
+}
+function unzip(z, passwords) {
 	let p = z.length - 22;
 	while (p >= 0 && !(z[p] === 0x50 && z[p + 1] === 0x4b && z[p + 2] === 5 && z[p + 3] === 6)) --p;
 	assert.ok(p >= 0, 'end of central directory');
@@ -131,7 +155,12 @@ function unzip(z) {
 		const name = Buffer.from(z.subarray(cd + 46, cd + 46 + nlen)).toString();
 		assert.strictEqual(dv.getUint32(off, true), 0x04034b50);
 		const lnlen = dv.getUint16(off + 26, true), lxlen = dv.getUint16(off + 28, true);
-		const body = z.subarray(off + 30 + lnlen + lxlen, off + 30 + lnlen + lxlen + csize);
+		let body = z.subarray(off + 30 + lnlen + lxlen, off + 30 + lnlen + lxlen + csize);
+		if (passwords) {
+			assert.strictEqual(dv.getUint16(off + 6, true) & 1, 1, 'ENCRYPT flag, local header');
+			assert.strictEqual(dv.getUint16(cd + 8, true) & 1, 1, 'ENCRYPT flag, central directory');
+			body = zipDecrypt(body, passwords[name] || passwords['*']);
+		}
 		const plain = method === 8 ? nodeZlib.inflateRawSync(Buffer.from(body)) : body;
 		assert.strictEqual(plain.length, usize, name);
 		assert.strictEqual(H.crc32(plain), crc, name);
@@ -153,6 +182,26 @@ it('Zip: STORE and DEFLATE entries, batched compress()', () => {
 	}
 	const files = unzip(zip.compress());
 	for (const key in td) assert.ok(H.equal(files[key], td[key]), key);
+});
+// zip-test.js:83-150 (compress with password: one for the archive, then one per file)
+it('Zip: compress with password (deflate)', () => {
+	const td = { hogehoge: H.makeText(30000, 1), fugafuga: inputs.sequential.subarray(0, 5000), piyopiyo: inputs.random.subarray(0, 4000) };
+	const zip = new Zlib.Zip();
+	zip.setPassword([0, 1, 2, 3, 4, 5, 6, 7, 8, 9]);
+	for (const key in td) zip.addFile(td[key], { filename: new Uint8Array(Buffer.from(key)) });
+	const files = unzip(zip.compress(), { '*': [0, 1, 2, 3, 4, 5, 6, 7, 8, 9] });
+	for (const key in td) assert.ok(H.equal(files[key], td[key]), key);
+});
+it('Zip: compress with password (each file)', () => {
+	const td = { hogehoge: [H.makeText(30000, 1), [1, 2, 3]], fugafuga: [inputs.sequential.subarray(0, 5000), [4, 5]], piyopiyo: [inputs.random.subarray(0, 4000), [6]] };
+	const zip = new Zlib.Zip();
+	const pw = {};
+	for (const key in td) {
+		zip.addFile(td[key][0], { filename: new Uint8Array(Buffer.from(key)), password: td[key][1], deflateOption: { compressionType: CT.FIXED } });
+		pw[key] = td[key][1];
+	}
+	const files = unzip(zip.compress(), pw);
+	for (const key in td) assert.ok(H.equal(files[key], td[key][0]), key);
 });
 it('Zip: many small files in one batch', () => {
 	const zip = new Zlib.Zip();
