@@ -1,6 +1,6 @@
 // Runs every stream of tests/golden/gpu_streams.json (output of the GPU path, made by
 // tools/make_gpu_streams.py on an MI355X) through the reference's own decoders under Node in
-// the build container: RawInflate, Inflate{verify}, Gunzip of the per-module sources, Unzip
+// the build container: RawInflate, Inflate{verify}, InflateStream, Gunzip of the per-module sources, Unzip
 // {verify} of the bundle (the per-module unzip.js cannot read archives with several entries).
 // The reference tree is read-only and lacks "type":"module": its src/ is copied to a scratch
 // directory at run time, as tests/golden/gen_golden.mjs does.
@@ -33,10 +33,11 @@ const sha = (u8) => crypto.createHash('sha256').update(Buffer.from(u8)).digest('
 	const { RawInflate } = await imp('src/rawinflate.js');
 	const { Inflate } = await imp('src/inflate.js');
 	const { Gunzip } = await imp('src/gunzip.js');
+	const { InflateStream } = await imp('src/inflate_stream.js');
 	const bundle = await imp('src/zlib.es.js');
 	const Unzip = bundle.Unzip || (bundle.Zlib && bundle.Zlib.Unzip) || (bundle.default && bundle.default.Unzip);
 	const fix = JSON.parse(fs.readFileSync(path.join(here, 'gpu_streams.json'), 'utf8'));
-	let ok = 0;
+	let ok = 0, streamed = 0;
 	const bad = [];
 	for (const s of fix.streams) {
 		const comp = new Uint8Array(Buffer.from(s.b64, 'base64'));
@@ -51,6 +52,24 @@ const sha = (u8) => crypto.createHash('sha256').update(Buffer.from(u8)).digest('
 			} else if (s.kind === 'zlib') {
 				const out = new Inflate(comp, { verify: true, bufferSize: Math.max(s.n, 1) }).decompress();
 				if (out.length !== s.n || sha(out) !== s.sha256) throw new Error('content differs: ' + out.length + ' bytes');
+				// and through the streaming inflater, fed in small pieces as the reference's own
+				// "(stream)" cases feed it (test/browser.es/staff/base.js:32-52)
+				const st = new InflateStream();
+				const parts = [];
+				let total = 0;
+				for (let i = 0; i < comp.length; i += 997) {
+					const buf = st.decompress(comp.subarray(i, Math.min(comp.length, i + 997)));
+					parts.push(new Uint8Array(buf)); // the inflater reuses its buffer: keep a copy
+					total += buf.length;
+				}
+				const whole = new Uint8Array(total);
+				let at = 0;
+				for (const p of parts) {
+					whole.set(p, at);
+					at += p.length;
+				}
+				if (total !== s.n || sha(whole) !== s.sha256) throw new Error('InflateStream: content differs: ' + total + ' bytes');
+				++streamed;
 			} else if (s.kind === 'gzip') {
 				const out = new Gunzip(comp).decompress(); // checks CRC-32 and ISIZE
 				if (out.length !== s.n || sha(out) !== s.sha256) throw new Error('content differs: ' + out.length + ' bytes');
@@ -69,7 +88,7 @@ const sha = (u8) => crypto.createHash('sha256').update(Buffer.from(u8)).digest('
 			bad.push(tag + ': ' + (e && e.message ? e.message : e));
 		}
 	}
-	console.log(JSON.stringify({ streams: fix.streams.length, ok, bad }));
+	console.log(JSON.stringify({ streams: fix.streams.length, ok, streamed, bad }));
 	process.exit(bad.length ? 1 : 0);
 })().catch((e) => {
 	console.error(e);

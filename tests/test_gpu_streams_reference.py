@@ -2,7 +2,8 @@
 tools/make_gpu_streams.py on an MI355X) against decoders that never saw the encoder:
 the oracle's strict inflater everywhere, and -- in the build container, where the reference
 tree and Node are present -- the reference's own RawInflate / Inflate / Gunzip / Unzip
-(tests/golden/check_gpu_streams.mjs).  No GPU is needed: the fixture is data."""
+(tests/golden/check_gpu_streams.mjs; zlib streams also through its InflateStream in pieces,
+encrypted archives through Unzip with the password).  No GPU is needed: the fixture is data."""
 import base64
 import hashlib
 import io
@@ -67,3 +68,4 @@ def test_gpu_streams_decode_with_the_reference_decoders():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
     assert res["ok"] == res["streams"] and not res["bad"]
+    assert res["streamed"] >= 10  # zlib streams also went through the reference's InflateStream in pieces
