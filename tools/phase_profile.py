@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["ZGPU_LIB"] = os.path.join(ROOT, "zlib.es_amd", "libzgpu_prof.so")
+os.environ["ZGPU_LIB"] = os.environ.get("ZGPU_PROF_LIB") or os.path.join(ROOT, "zlib.es_amd", "libzgpu_prof.so")
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import zlib_es_amd as z  # noqa: E402

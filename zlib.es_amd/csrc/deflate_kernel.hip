@@ -801,6 +801,9 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 if (lane == 0) {
                     for (;;) {
                         if (atomicCAS(&misc[M_LOCK], 0u, 1u) != 0u) break;  // someone else is at it
+                        // the frontier is one lane's serial walk that every wave's hand-offs hang on: while it
+                        // runs, this wave's instructions go first among the four waves of its SIMD
+                        __builtin_amdgcn_s_setprio(3);
                         uint32_t f = lds_ld(&misc[M_PARSE]), e = lds_ld(&misc[M_ENTRY]), t = lds_ld(&misc[M_NTOK]),
                                  safe = lds_ld(&misc[M_SAFE]);
                         uint32_t stamp = lds_ld(&slot_done[f & (NSLOT - 1)]);
@@ -828,6 +831,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         lds_st(&misc[M_SAFE], safe);
                         lds_st(&misc[M_PARSE], f);
                         lds_st(&misc[M_LOCK], 0u);
+                        __builtin_amdgcn_s_setprio(0);
                         // an item stamped while the lock was held must not be left behind; nor a
                         // bound that moved (a wave that moves it after this look finds M_PARSE
                         // at the bound and advances the frontier itself)
@@ -888,6 +892,9 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     s_tok = lds_ld(&slot_tokb[sl]);
                 }
                 asm volatile("" ::: "memory");
+                // tokens out = this wave's oldest-item word moves on, which is what the frontier's bound
+                // waits for: slightly ahead of the bulk search work of the SIMD's other waves
+                __builtin_amdgcn_s_setprio(1);
                 PH_END(15);
                 // local index of the first token (>= seg_end: a match from before covers the item)
                 const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ent) - p0;
@@ -942,6 +949,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     q_rhi[i] = q_rhi[i + 1];
                 }
                 --npend;
+                __builtin_amdgcn_s_setprio(0);
                 PH_END(7);
                 if (frontier_held) try_advance();
                 return true;
@@ -954,6 +962,13 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 if (lane == 0) t = atomicAdd(&misc[M_ITEM], 1u);
                 t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
                 if (t >= blk_end + AHEAD) break;
+                // From the ticket to the end of its linking turn an item is on the workgroup's one serial
+                // chain: the turns are taken in ticket order, so whatever delays this wave on its way to the
+                // turn (hash, sort, issue slots lost to the other three waves of its SIMD) delays every
+                // item behind it.  The wave runs that stretch at raised priority and drops back for the
+                // bulk of its work (walks, scoring, parse tables), which only its own item waits for.
+                // Measured on the 64 KiB-unit bench: waiting for the turn 1.1 -> 0.3 cycles per input byte.
+                __builtin_amdgcn_s_setprio(2);
                 const bool has_search = t >= AHEAD;  // tickets below AHEAD (the unit's first) only link
                 const uint32_t k = t - AHEAD;        // the searched item (valid when has_search)
                 PH_START();
@@ -972,15 +987,21 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 }
                 const uint32_t p0 = has_search ? k << 6 : 0u;
                 const uint32_t p = p0 + (uint32_t)lane;
-                // ring refill every 16 KiB, by the wave that crosses the boundary
-                if (has_search && k && (p0 & (REFILL - 1)) == 0) {
-                    uint32_t lo = p0 + REFILL, hi = p0 + 2 * REFILL;
-                    if (hi > n) hi = n;
-                    if (lo < hi) {
-                        load_ring<RING>(ring, in, lo, hi, lane, 64, aligned);
-                        lds_publish(&misc[M_LOADED], hi);
+                // Ring refill every 16 KiB, by the wave that crosses the boundary -- but only after it has
+                // stamped its item (end of this iteration): the bytes are for items a quarter of the ring ahead,
+                // which cannot start before this item is parsed (LAG) and wait for M_LOADED in any case, while
+                // a 16 KiB global load in front of the linking turn held up every item behind this one, and in
+                // front of the search it held up the parse frontier.
+                auto refill = [&]() {
+                    if (has_search && k && (p0 & (REFILL - 1)) == 0) {
+                        uint32_t lo = p0 + REFILL, hi = p0 + 2 * REFILL;
+                        if (hi > n) hi = n;
+                        if (lo < hi) {
+                            load_ring<RING>(ring, in, lo, hi, lane, 64, aligned);
+                            lds_publish(&misc[M_LOADED], hi);
+                        }
                     }
-                }
+                };
                 {
                     uint32_t need = p0 + LOOKAHEAD;  // covers the linked item (AHEAD items on) as well
                     if (need > n) need = n;
@@ -1025,6 +1046,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     const uint32_t hv = *(const uint16_t *)(lds_raw + roff);
                     *(uint16_t *)(lds_raw + woff) = (uint16_t)mypos;
                     lds_publish(&misc[M_LINK], t + 1);
+                    __builtin_amdgcn_s_setprio(0);
                     if (first) pp = hv;
                     const uint32_t linked = lds_ld(&misc[M_LINKED]);
                     if (live) prevt[mypos & WMASK] = (uint16_t)pp;
@@ -1033,6 +1055,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 } else {
                     // past the unit's last item: the items this search reads links of are all linked
                     lds_wait_ge(&misc[M_LINKED], nitems);
+                    __builtin_amdgcn_s_setprio(0);
                 }
                 PH_END(11);
                 if (!has_search) continue;
@@ -1467,6 +1490,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 // frontier on its way here either sees the stamp, or publishes M_PARSE = k after
                 // this look and then looks at the stamp again (the check after its unlock).
                 if (lds_ld(&misc[M_PARSE]) == k) try_advance();
+                refill();
             }
             if (blk_end == nitems) {
                 // out of items in the unit's last block: request the next unit's first bytes
