@@ -1453,6 +1453,17 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     // and the positions visited on the way (this one included), for the token step
                     r_lo = (uint32_t)lane < seg_end && lane < 32 ? 1u << lane : 0u;
                     r_hi = (uint32_t)lane < seg_end && lane >= 32 ? 1u << (lane - 32) : 0u;
+                    // an item without a single match (incompressible data): every index walks literal by
+                    // literal to the item's end -- exit, count and visited set in closed form, no doubling
+                    if (!__ballot(kind != 0u)) {
+                        if ((uint32_t)lane < seg_end) {
+                            const unsigned long long m = (seg_end == 64u ? ~0ull : (1ull << seg_end) - 1ull) & ~((1ull << lane) - 1ull);
+                            J = seg_end;
+                            Cn = seg_end - (uint32_t)lane;
+                            r_lo = (uint32_t)m;
+                            r_hi = (uint32_t)(m >> 32);
+                        }
+                    } else
 #pragma unroll
                     for (int r = 0; r < 6; ++r) {
                         // every index already leaves the item (long matches): nothing left to double
