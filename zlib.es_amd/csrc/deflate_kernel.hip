@@ -1934,12 +1934,17 @@ __device__ __forceinline__ void emit_units(const EParams &P, uint8_t *lds) {
             PH_END(2);
             const uint32_t mL = misc[M_NTOK], mD = misc[M_TMP];
             // ---- the two trees, one wave each ----
+            // the tree builders and the header are one or two waves' serial work that the rest of the
+            // workgroup waits for at the barrier: they go first among the waves the other workgroups of
+            // the CU have on the same SIMDs (emit kernel 5.14 -> 4.60 ms on 64 KiB units)
+            __builtin_amdgcn_s_setprio(3);
             if (wave == 0) wave_huffman<5>(TL, mL, 286, 15, lltab);
             if (NT == 64) PH_END(3);
             if (wave == (NT == 64 ? 0 : 1)) wave_huffman<1>(TD, mD, 30, 15, dtab);
             group_sync<NT>();
             PH_END(4);
             if (wave == 0) header_fields();
+            __builtin_amdgcn_s_setprio(0);
         } else {
             // fixed Huffman codes (RFC 1951 3.2.6; FixedHuffmanTable rawdeflate.js:48-68)
             for (int sy = tid; sy < 288; sy += EWG) {
