@@ -702,6 +702,13 @@ __device__ __forceinline__ void search_units(const Params &P) {
         const uint32_t prime_items = pr >> 6;
         uint16_t *tokbuf = P.tok + ((uint64_t)misc[M_NEXT + 5] | (uint64_t)misc[M_NEXT + 6] << 32);  // of the block in progress
         const uint32_t unit_blk_first = misc[M_NEXT + 7];
+        // Lower bounds of the parse frontier and of the ring's fill level that this wave has seen (both only
+        // grow within a unit): an item whose bounds they already satisfy starts without reading the words --
+        // two dependent LDS round trips fewer on the way to its linking turn.  Only in the variant with one
+        // workgroup per CU: the others run at 64 registers per lane and pay for two more live values with
+        // spills (zip workload +6 % search time when they carried them).
+        constexpr bool CACHE_BOUNDS = C::WG_PER_CU == 1;
+        uint32_t seen_parse = 0, seen_loaded = 0;
 
         // ---- unit init ----
         for (int i = tid; i < (1 << HBITS) / 8; i += WG)
@@ -892,6 +899,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     s_tok = lds_ld(&slot_tokb[sl]);
                 }
                 asm volatile("" ::: "memory");
+                if constexpr (CACHE_BOUNDS) seen_parse = (uint32_t)__builtin_amdgcn_readfirstlane((int)fr);
                 // tokens out = this wave's oldest-item word moves on, which is what the frontier's bound
                 // waits for: slightly ahead of the bulk search work of the SIMD's other waves
                 __builtin_amdgcn_s_setprio(1);
@@ -983,7 +991,14 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     while (npend > 0 && k > q_k[0] + LAG) emit_oldest(k, true);
                     // bound the spread of in-flight items: everything more than LAG items back is
                     // parsed, so no wave still reads ring bytes or chain slots that get recycled
-                    if (k > LAG) lds_wait_ge(&misc[M_PARSE], k - LAG);
+                    if constexpr (!CACHE_BOUNDS) {
+                        if (k > LAG) lds_wait_ge(&misc[M_PARSE], k - LAG);
+                    } else if (k > LAG && (int32_t)(seen_parse - (k - LAG)) < 0) {
+                        uint32_t f;
+                        while ((int32_t)((f = lds_ld(&misc[M_PARSE])) - (k - LAG)) < 0) __builtin_amdgcn_s_sleep(0);
+                        asm volatile("" ::: "memory");
+                        seen_parse = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
+                    }
                 }
                 const uint32_t p0 = has_search ? k << 6 : 0u;
                 const uint32_t p = p0 + (uint32_t)lane;
@@ -1005,7 +1020,14 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 {
                     uint32_t need = p0 + LOOKAHEAD;  // covers the linked item (AHEAD items on) as well
                     if (need > n) need = n;
-                    lds_wait_ge(&misc[M_LOADED], need);
+                    if constexpr (!CACHE_BOUNDS) {
+                        lds_wait_ge(&misc[M_LOADED], need);
+                    } else if ((int32_t)(seen_loaded - need) < 0) {
+                        uint32_t f;
+                        while ((int32_t)((f = lds_ld(&misc[M_LOADED])) - need) < 0) __builtin_amdgcn_s_sleep(0);
+                        asm volatile("" ::: "memory");
+                        seen_loaded = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
+                    }
                 }
                 PH_END(8);
                 // this position's first 16 bytes: compared against candidates below
