@@ -1196,14 +1196,20 @@ __device__ __forceinline__ void search_units(const Params &P) {
                                     len = cmpmax;
                                 }
                                 c = nxt;
-                                if (len > blen) {
-                                    blen = len;
-                                    best_dist = dist;
+                                {
+                                    // selects, not a branch: every branch the wave can diverge on costs a
+                                    // handful of scalar instructions per candidate, and the scalar unit is
+                                    // shared by all waves of the CU (search kernel 75.3 -> 74.1 ms).  A loop
+                                    // with one exit per candidate -- the next link's range test folded into
+                                    // it -- was 2 ms slower than this one.
+                                    const bool better = len > blen;
+                                    blen = better ? len : blen;
+                                    best_dist = better ? dist : best_dist;
                                     // as long as the unit allows, or as long as the caller finds nice
                                     // (nice <= CMP_CAP, the default: the first capped candidate ends
                                     // the walk; pass 2 finds its exact length and the long-match
                                     // steps below look for longer ones)
-                                    if (len >= maxlen || len >= (uint32_t)P.nice) break;
+                                    if (better && (len >= maxlen || len >= (uint32_t)P.nice)) break;
                                 }
                             }
                         }
