@@ -1304,6 +1304,8 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             unsigned long long sm = starts();
                             bool go = ((sm >> lane) & 1ull) && last != 0xffffu;
                             if (__ballot(go)) {
+                                // one or two lanes' dependent chain with the whole wave behind it
+                                __builtin_amdgcn_s_setprio(3);
                                 // A match longer than the best one, at whatever distance, repeats the four
                                 // bytes that straddle the best one's end (three inside, one after) at that
                                 // distance: the candidate is on the chain of the position t that starts those
@@ -1387,6 +1389,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                                 }
                             }
                         }
+                        __builtin_amdgcn_s_setprio(0);
                         PH_END(2);
                         // probe ahead: the positions after a start lane were linked to the nearest
                         // earlier occurrence of their own four bytes; the distance of such a link,
