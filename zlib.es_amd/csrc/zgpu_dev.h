@@ -21,3 +21,8 @@
 #define ZGPU_CKW_THREADS 1024
 #define ZGPU_CKW_SEG (4u << 20)
 #define ZGPU_CKW_MIN_BYTES (64ull << 20)
+// consecutive 16-byte pieces a lane folds per round (1, 2 or 4), and the entries of the x^(128 * 2^lv) table
+#ifndef ZGPU_CKW_PIECES
+#define ZGPU_CKW_PIECES 2
+#endif
+#define ZGPU_CKW_XPOW 12
