@@ -97,6 +97,23 @@ bool make_output_buffer(napi_env env, uint64_t room, void **data, napi_value *ab
     return napi_create_arraybuffer(env, (size_t)room, data, ab) == napi_ok;
 }
 
+// Inputs that do not lie back to back are gathered here before they go to the library.  One mapping
+// for the life of the process, grown when a call needs more (calls come from the one JavaScript thread).
+uint8_t *gather_buffer(size_t need) {
+    static uint8_t *buf = nullptr;
+    static size_t cap = 0;
+    if (need <= cap) return buf;
+    const size_t kHuge = 2u << 20;
+    const size_t len = (need + need / 4 + kHuge - 1) / kHuge * kHuge;
+    void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) return nullptr;
+    (void)madvise(p, len, MADV_HUGEPAGE);
+    if (buf) munmap(buf, cap);
+    buf = (uint8_t *)p;
+    cap = len;
+    return buf;
+}
+
 napi_value throw_zgpu(napi_env env, const char *what, int rc) {
     std::string msg = std::string(what) + ": " + (g.strerror_ ? g.strerror_(rc) : "libzgpu error") +
                       " (code " + std::to_string(rc) + ")";
@@ -292,14 +309,14 @@ napi_value DeflateBatch(napi_env env, napi_callback_info info) {
             if (!first) first = ptrs[i] - in_off[i];
             contiguous = ptrs[i] == first + in_off[i];
         }
-        std::unique_ptr<uint8_t[]> flat;
         const uint8_t *src = first;
         if (!contiguous || !first) {
-            flat.reset(new (std::nothrow) uint8_t[in_off[n] ? in_off[n] : 1]);
+            // the gathering buffer is kept between calls (it only grows): pages touched once stay
+            uint8_t *flat = gather_buffer(in_off[n] ? in_off[n] : 1);
             if (!flat) return throw_zgpu(env, "staging buffer", -3);
             for (uint32_t i = 0; i < n; ++i)
-                if (in_off[i + 1] > in_off[i]) memcpy(flat.get() + in_off[i], ptrs[i], in_off[i + 1] - in_off[i]);
-            src = flat.get();
+                if (in_off[i + 1] > in_off[i]) memcpy(flat + in_off[i], ptrs[i], in_off[i + 1] - in_off[i]);
+            src = flat;
         }
         // Two steps: compress, learn the size, then let the library copy into an ArrayBuffer of exactly
         // that size (see make_output_buffer).
@@ -317,7 +334,6 @@ napi_value DeflateBatch(napi_env env, napi_callback_info info) {
                 if (job) g.job_release(job);
             }
         } guard{job};
-        flat.reset();
         uint64_t room = total;
         if (gaps) {
             for (uint32_t i = 0; i < n; ++i) room += gaps[i];
