@@ -289,6 +289,36 @@ it('RawDeflate.compressBatch', () => {
 	ins.forEach((d, i) => assert.ok(H.equal(nodeZlib.inflateRawSync(Buffer.from(outs[i])), d), 'unit ' + i));
 });
 
+// results of 4 MiB and more come in a buffer the addon maps itself (huge pages) and hands over as an
+// external ArrayBuffer: the views, a zip archive framed inside such a buffer, and many buffers made and dropped
+it('large results: externally mapped output buffers', () => {
+	const rnd = new Uint8Array(6 << 20);
+	let x = 99;
+	for (let i = 0; i < rnd.length; i += 4) {
+		x = (Math.imul(x, 1664525) + 1013904223) >>> 0;
+		rnd[i] = x; rnd[i + 1] = x >>> 8; rnd[i + 2] = x >>> 16; rnd[i + 3] = x >>> 24;
+	}
+	let lastByte = -1;
+	for (let round = 0; round < 6; ++round) {
+		const one = new Zlib.RawDeflate(rnd, { compressionType: CT.DYNAMIC }).compress();
+		assert.ok(one.length >= rnd.length && one.byteOffset === 0);
+		if (round === 0) assert.ok(H.equal(nodeZlib.inflateRawSync(Buffer.from(one)), rnd));
+		else assert.strictEqual(one[one.length - 1], lastByte);
+		lastByte = one[one.length - 1];
+	}
+	const parts = [];
+	for (let i = 0; i < 24; ++i) parts.push(rnd.subarray(i << 18, (i + 1) << 18));
+	const outs = Zlib.RawDeflate.compressBatch(parts, { compressionType: CT.FIXED });
+	assert.strictEqual(outs[0].buffer, outs[23].buffer);
+	assert.ok(outs[0].buffer.byteLength >= 4 << 20);
+	parts.forEach((d, i) => assert.ok(H.equal(nodeZlib.inflateRawSync(Buffer.from(outs[i])), d), 'part ' + i));
+	const zip = new Zlib.Zip();
+	parts.forEach((d, i) => zip.addFile(d, { filename: new Uint8Array(Buffer.from('p' + i)) }));
+	const files = unzip(zip.compress());
+	parts.forEach((d, i) => assert.ok(H.equal(files['p' + i], d), 'entry ' + i));
+	if (global.gc) global.gc();
+});
+
 // ---- Node wrapper, compress side (test/nodejs/node-test.js:101-131, node/exports.js:52-69,150-165) ----
 it('deflateSync / gzipSync return Buffers that Node inflates', () => {
 	const W = require('../zlib_gpu.js');
