@@ -25,7 +25,7 @@
 typedef struct {
     int chain;        /* candidates per walk */
     int cap;          /* pass-1 compare cap */
-    int stop_at_cap;  /* 1: first capped candidate ends the walk (shipped round 1) */
+    int stop_at_cap;  /* 1: first capped candidate ends the walk (the shipped default) */
     int share_min;    /* offers need at least this length */
     int share_iters;  /* distinct distances scored per item */
     int share_order;  /* 0 lowest lane first, 1 highest lane first, 2 longest first */
@@ -44,6 +44,7 @@ typedef struct {
     int fan_from0;    /* 1: probes start at j = 0 instead of at the tail of the current best */
     int fan_maxd;     /* a lane fans only when its best distance is at most this (0 = any) */
     int fan_depth;    /* links followed along the chain of each probed position (0 = 1) */
+    int cert;         /* 1: a deep walk ends (or does not start) when the four bytes that straddle the end of the best match have no earlier occurrence: nothing longer exists */
     int itemfast;     /* 1: an item whose 64 positions all repeat at lane 0's nearest candidate distance takes that distance and skips the search */
 } Policy;
 static uint64_t g_fans, g_fast;
@@ -419,7 +420,15 @@ static uint64_t simulate(uint32_t n, const Policy *P, int ctype, uint64_t *walk_
                 uint32_t last = c >= 0 ? 0 : 0;
                 int st = 0;
                 uint32_t lastd = 0;
+                int need_cert = 1;
                 for (int b = P->deep; b > 0 && c >= 0; --b) {
+                    if (P->cert && need_cert) {
+                        need_cert = 0;
+                        ++st;
+                        uint32_t t = p + blen[l] - 3;
+                        int32_t c2 = prevp[t];
+                        if (c2 < 0 || t - (uint32_t)c2 > limit || memcmp(data + c2, data + t, 4)) break;
+                    }
                     uint32_t dist = p - (uint32_t)c;
                     if (dist <= lastd || dist > limit) break;
                     lastd = dist;
@@ -431,6 +440,7 @@ static uint64_t simulate(uint32_t n, const Policy *P, int ctype, uint64_t *walk_
                         if (len > bl) {
                             blen[l] = len;
                             bd[l] = dist;
+                            need_cert = 1;
                             if (nnew < 64) newd[nnew++] = dist;
                             if (len >= maxlen) break;
                         }
@@ -584,8 +594,8 @@ int main(int argc, char **argv) {
         {"rnd76543", 0, 76543, 1, 0},
     };
     const int ncases = sizeof cases / sizeof cases[0];
-    /* policies: name=value pairs on the command line override the round-1 defaults */
-    Policy P = {8, 32, 1, 16, 6, 0, 0, 0, 258, 4096, 0, 0, 1, 0, 0, 32, 4, 0, 0, 0, 0, 0};
+    /* policies: name=value pairs on the command line override the defaults below */
+    Policy P = {8, 32, 1, 16, 6, 0, 0, 0, 258, 4096, 0, 0, 1, 0, 0, 32, 4, 0, 0, 0, 0, 0, 0};
     for (int a = 1; a < argc; ++a) {
         char key[32];
         int v;
@@ -593,7 +603,7 @@ int main(int argc, char **argv) {
 #define K(name) if (!strcmp(key, #name)) P.name = v
         K(chain); K(cap); K(stop_at_cap); K(share_min); K(share_iters); K(share_order); K(keep); K(deep);
         K(lazy); K(min3dist); K(dist1); K(exact_own); K(start_only); K(tail_all);
-        K(fan); K(fan_min); K(fan_stride); K(fan_try); K(fan_from0); K(fan_maxd); K(fan_depth); K(itemfast);
+        K(fan); K(fan_min); K(fan_stride); K(fan_try); K(fan_from0); K(fan_maxd); K(fan_depth); K(itemfast); K(cert);
 #undef K
     }
     g_dump = getenv("DUMP") != NULL;
