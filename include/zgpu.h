@@ -119,16 +119,24 @@ int zgpu_set_search(int max_chain, int nice_length);
  * more than the nearest long candidate; the reference finds the longest of all
  * (src/rawdeflate.js:370-395).  deep_chain: further candidates such a position
  * examines along its chain, each looked at only if it agrees in the byte after
- * the current best (0..32768, default 0: every step is a dependent LDS round
- * trip).  The walk ends by itself where nothing longer can exist -- when the
+ * the current best (0..32768, default 96; every step is a dependent LDS round
+ * trip, so only run-like input pays: text and incompressible input never get
+ * here).  The walk ends by itself where nothing longer can exist -- when the
  * four bytes that straddle the end of the best match occur nowhere earlier
- * within reach -- so a budget beyond about 128 costs nothing more.
- * probe_fans: such positions per 64 input bytes whose match lies at most 16
- * bytes back (runs, short periods) that also try the distances at which the
- * positions up to 256 bytes after them repeat (0..64, default 1).  (128, 1)
- * brings runs of incrementing bytes from 1.27-1.35 x the reference's size to
- * 1.005-1.02 x at about 55 % of the default's speed on such input (80 % on a
- * mix that holds a quarter of it); (32, 1): 1.02-1.04 x at 70 % / 90 %. */
+ * within reach -- so a budget beyond about 128 costs nothing more.  With the
+ * deep walk on, items that lie in long copies walk three candidates per
+ * position instead of max_chain.
+ * With the deep walk on, a position whose match repeats at a distance of at
+ * most 16 bytes (a run, a short period) also walks up to eight candidates
+ * along the chain of the position where its match ends -- the places where
+ * the run ended the same way before -- which is what finds the matches across
+ * run ends that the reference finds (4-value runs: 1.05-1.08 x -> 1.00-1.02 x
+ * the reference's size under FIXED).  probe_fans (0..64) selected an earlier
+ * step that these walks made redundant; the value is checked and ignored.
+ * Runs of incrementing bytes (the reference tests' makeRandomSequentialData)
+ * are 1.27-1.35 x the reference's size at deep_chain 0, 1.03 x at 64,
+ * 1.01-1.02 x at 96, the default, and at 128; such input runs at about 80 % of
+ * its deep_chain 0 speed with the default. */
 int zgpu_set_long_match(int deep_chain, int probe_fans);
 /* In a batch of fewer than 16 units per compute unit, a unit longer than two
  * pieces is cut into pieces (batch bytes / 16 / compute units, at least

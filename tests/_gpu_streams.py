@@ -26,7 +26,7 @@ SPECS = [
     {"gen": "text", "n": 400000, "seed": 9},   # cut into pieces inside one call
 ]
 # search settings other than the defaults: (name, max_chain, nice_length, deep_chain, probe_fans)
-VARIANTS = [("thorough", 8, 64, 0, 1), ("long-match", 8, 32, 128, 3)]
+VARIANTS = [("thorough", 8, 64, 0, 1), ("long-match", 8, 32, 128, 3), ("no-deep-walk", 8, 32, 0, 1)]
 VARIANT_SPECS = [{"gen": "rndseq", "n": 76543, "seed": 1346432776267}, {"gen": "text", "n": 65536, "seed": 42},
                  {"gen": "runs", "n": 65536, "seed": 3}]
 JS_SPECS = [{"gen": "bytes", "hex": b"abcabcabcabcXabcabc".hex()}, {"gen": "text", "n": 65536, "seed": 42},

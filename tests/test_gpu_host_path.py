@@ -139,9 +139,9 @@ def test_knobs_are_read_when_a_plan_is_created(z):
         return int(o[1])
 
     try:
-        N.set_long_match(64, 3)
+        N.set_long_match()  # the default walks on past the first long candidate
         deep_plan = z.Plan(off, 2, 0, N.F_FINAL_EACH)
-        N.set_long_match()
+        N.set_long_match(0, 1)
         fast_plan = z.Plan(off, 2, 0, N.F_FINAL_EACH)
         assert run(deep_plan) < run(fast_plan)  # the plan kept what it read, whatever was set later
     finally:

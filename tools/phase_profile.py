@@ -17,7 +17,7 @@ import bench  # noqa: E402
 import zlib_es_amd as z  # noqa: E402
 
 EPHASES = ["queue", "hist", "sort", "treeL", "treeD", "rle", "treeCL", "hdrbits", "tokens", "finish"]
-PHASES = ["load", "blkwait", "deep", "fan", "-", "-", "-", "emit-tok", "lag+ld", "sort", "linkwait", "link", "pass1", "pass2", "prep", "parsewait"]
+PHASES = ["load", "blkwait", "deep", "fan", "horizon", "cert", "deepwalk", "emit-tok", "lag+ld", "sort", "linkwait", "link", "pass1", "pass2", "prep", "parsewait"]
 
 
 def run(name, data, nu, ub, ctype, lazy):
@@ -57,10 +57,15 @@ def main():
     full = bench.gen_units(int(os.environ.get("GEN", 20 * 512)), ub, 7, dev).view(-1, ub)
     kinds = {"text": (0, 10), "binary": (10, 15), "random": (15, 18), "lowent": (18, 20)}
     idx = torch.arange(full.shape[0], device=dev) % 20
+    only = os.environ.get("KINDS")  # e.g. "binary,mixed"
     for name, (a, b) in kinds.items():
+        if only and name not in only.split(","):
+            continue
         rows = full[(idx >= a) & (idx < b)][:nu].contiguous()
         n = rows.shape[0]
         run(name, rows.view(-1), n, ub, 2, 0)
+    if only and "mixed" not in only.split(","):
+        return
     mixed = full[:nu].contiguous()
     run("mixed", mixed.view(-1), mixed.shape[0], ub, 2, 0)
     run("mixed-fx", mixed.view(-1), mixed.shape[0], ub, 1, 0)

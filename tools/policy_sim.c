@@ -45,6 +45,17 @@ typedef struct {
     int fan_maxd;     /* a lane fans only when its best distance is at most this (0 = any) */
     int fan_depth;    /* links followed along the chain of each probed position (0 = 1) */
     int cert;         /* 1: a deep walk ends (or does not start) when the four bytes that straddle the end of the best match have no earlier occurrence: nothing longer exists */
+    int run_stop;     /* > 0: after this many candidates the walk ends for the whole item when at least run_frac lanes hold a capped match */
+    int run_frac;
+    int lane0;        /* 1: the item's first position is not a start lane when the byte before it repeats at its best distance */
+    int run_same;     /* > 0: an item with at least this many such lanes walks run_stop candidates */
+    int tailwalk;     /* > 0: start lanes walk this many candidates along the chain of the straddle position */
+    int tail_lane0;   /* 1: the item's first position tail-walks even when it continues a match */
+    int tail_maxd;    /* tail walks only from matches at most this far back (0 = any) */
+    int seqrule;      /* 1: a deep walk ends when its chain runs through four consecutive positions */
+    int maxstart;     /* 1: a position whose predecessor's match has the maximum length is a start lane for the tail walk */
+    int tail_restart; /* after an improvement: 0 go on along the same chain, 1 start over at the new straddle position, 2 go on, and start over when the chain ends */
+    int run_lag;      /* > 0: the rule looks at the item this many items back instead of at the item itself */
     int itemfast;     /* 1: an item whose 64 positions all repeat at lane 0's nearest candidate distance takes that distance and skips the search */
 } Policy;
 static uint64_t g_fans, g_fast;
@@ -53,6 +64,7 @@ static uint8_t data[MAXN + 512];
 static int32_t prevp[MAXN];
 static int32_t headp[1 << HBITS];
 static uint32_t best_len[MAXN], best_dist[MAXN];
+static uint8_t item_flag[MAXN / 64 + 1];
 
 static inline uint32_t hash4(const uint8_t *p) {
     uint32_t w;
@@ -293,59 +305,106 @@ static uint64_t simulate(uint32_t n, const Policy *P, int ctype, uint64_t *walk_
                 continue;
             }
         }
-        for (uint32_t l = 0; l < cnt; ++l) {
-            uint32_t p = p0 + l;
-            uint32_t maxlen = n - p < 258 ? n - p : 258;
-            uint32_t limit = p < MAXDIST ? p : MAXDIST;
-            uint32_t cmpmax = maxlen < (uint32_t)P->cap ? maxlen : (uint32_t)P->cap;
-            if (p + 4 > n) continue;
-            int32_t c = prevp[p];
-            uint32_t last = 0;
-            int st = 0;
-            int budget = P->chain;
-            int capped_seen = 0;
-            for (; budget > 0; --budget) {
-                if (c < 0) break;
-                uint32_t dist = p - (uint32_t)c;
-                if (dist <= last || dist > limit) break;
-                last = dist;
-                ++st;
-                uint32_t len;
-                if (capped_seen && P->tail_all) {
-                    /* tail check against the exact current best, then full compare */
-                    uint32_t bl = blen[l];
-                    if (bl < maxlen && data[c + bl] == data[p + bl] && data[c + bl - 1] == data[p + bl - 1])
-                        len = mlen(data + p, data + c, maxlen);
-                    else
-                        len = 0;
-                } else {
-                    len = mlen(data + p, data + c, cmpmax);
-                }
-                int32_t nxt = prevp[c];
-                if (len > blen[l]) {
-                    blen[l] = len;
-                    bd[l] = dist;
-                    if (len >= maxlen) {
-                        c = nxt;
-                        break;
-                    }
-                    if (len >= cmpmax && !capped_seen) {
-                        capped_seen = 1;
-                        if (P->stop_at_cap) {
-                            c = nxt;
-                            --budget;
-                            break;
-                        }
-                        if (P->tail_all) blen[l] = mlen(data + p, data + c, maxlen);
-                    }
-                } else if (len >= cmpmax && capped_seen && !P->tail_all && noff[l] < (uint32_t)P->keep) {
-                    offers[l][noff[l]++] = dist;
-                }
-                c = nxt;
+        /* the lanes of an item walk in lock-step (as the wave does), so that rules that look at the
+         * whole item between candidates can be modelled */
+        {
+            int32_t wc[64];
+            uint32_t wlast[64];
+            int walking[64], capseen[64], wst[64], wbudget[64];
+            for (uint32_t l = 0; l < 64; ++l) {
+                walking[l] = 0;
+                capseen[l] = 0;
+                wst[l] = 0;
+                wbudget[l] = P->chain;
+                wlast[l] = 0;
+                wc[l] = -1;
             }
-            cursor[l] = c;
-            budget_left[l] = budget;
-            if (st > maxsteps) maxsteps = st;
+            for (uint32_t l = 0; l < cnt; ++l) {
+                if (p0 + l + 4 > n) continue;
+                walking[l] = 1;
+                wc[l] = prevp[p0 + l];
+            }
+            int chain_here = P->chain;
+            if (P->run_lag && P->run_stop) {
+                /* the item run_lag items back (parsed before this one may start) was run-like: this one
+                 * walks run_stop candidates only */
+                uint32_t kk = p0 >> 6;
+                if (kk >= (uint32_t)P->run_lag && item_flag[kk - P->run_lag]) chain_here = P->run_stop;
+            }
+            if (P->run_same && P->run_stop) {
+                /* lanes whose nearest candidate lies at the same distance as their left neighbour's: inside copies */
+                int same = 0;
+                for (uint32_t l = 1; l < cnt; ++l)
+                    if (walking[l] && walking[l - 1] && wc[l] >= 0 && wc[l - 1] >= 0 && wc[l] == wc[l - 1] + 1) ++same;
+                if (same >= P->run_same) chain_here = P->run_stop;
+            }
+            for (int step = 0; step < chain_here; ++step) {
+                if (!P->run_lag && P->run_stop && step == P->run_stop) {
+                    /* run-like item: at least run_frac lanes hold a capped match -- the others lie in
+                     * the shadow of long matches and stop walking */
+                    int capped = 0;
+                    for (uint32_t l = 0; l < cnt; ++l) capped += blen[l] >= (uint32_t)P->cap;
+                    if (capped >= P->run_frac) break;
+                }
+                int any = 0;
+                for (uint32_t l = 0; l < cnt; ++l) {
+                    if (!walking[l]) continue;
+                    uint32_t p = p0 + l;
+                    uint32_t maxlen = n - p < 258 ? n - p : 258;
+                    uint32_t limit = p < MAXDIST ? p : MAXDIST;
+                    uint32_t cmpmax = maxlen < (uint32_t)P->cap ? maxlen : (uint32_t)P->cap;
+                    int32_t c = wc[l];
+                    if (c < 0) { walking[l] = 0; continue; }
+                    uint32_t dist = p - (uint32_t)c;
+                    if (dist <= wlast[l] || dist > limit) { walking[l] = 0; continue; }
+                    wlast[l] = dist;
+                    ++wst[l];
+                    any = 1;
+                    uint32_t len;
+                    if (capseen[l] && P->tail_all) {
+                        uint32_t bl = blen[l];
+                        if (bl < maxlen && data[c + bl] == data[p + bl] && data[c + bl - 1] == data[p + bl - 1])
+                            len = mlen(data + p, data + c, maxlen);
+                        else
+                            len = 0;
+                    } else {
+                        len = mlen(data + p, data + c, cmpmax);
+                    }
+                    int32_t nxt = prevp[c];
+                    --wbudget[l];
+                    if (len > blen[l]) {
+                        blen[l] = len;
+                        bd[l] = dist;
+                        if (len >= maxlen) {
+                            wc[l] = nxt;
+                            walking[l] = 0;
+                            continue;
+                        }
+                        if (len >= cmpmax && !capseen[l]) {
+                            capseen[l] = 1;
+                            if (P->stop_at_cap) {
+                                wc[l] = nxt;
+                                walking[l] = 0;
+                                continue;
+                            }
+                            if (P->tail_all) blen[l] = mlen(data + p, data + c, maxlen);
+                        }
+                    } else if (len >= cmpmax && capseen[l] && !P->tail_all && noff[l] < (uint32_t)P->keep) {
+                        offers[l][noff[l]++] = dist;
+                    }
+                    wc[l] = nxt;
+                }
+                if (any) ++maxsteps;
+            }
+            {
+                int capped = 0;
+                for (uint32_t l = 0; l < cnt; ++l) capped += blen[l] >= (uint32_t)P->cap;
+                item_flag[p0 >> 6] = capped >= P->run_frac;
+            }
+            for (uint32_t l = 0; l < cnt; ++l) {
+                cursor[l] = wc[l];
+                budget_left[l] = wbudget[l];
+            }
         }
         steps += (uint64_t)maxsteps;
         /* pass 2: share distances */
@@ -405,7 +464,7 @@ static uint64_t simulate(uint32_t n, const Policy *P, int ctype, uint64_t *walk_
             }
         }
         /* pass 3: deep walk with the tail check */
-        if (P->deep > 0) {
+        if (P->deep > 0 || P->tailwalk > 0) {
             int mx = 0;
             uint32_t newd[64];
             int nnew = 0;
@@ -413,6 +472,9 @@ static uint64_t simulate(uint32_t n, const Policy *P, int ctype, uint64_t *walk_
                 uint32_t p = p0 + l;
                 if (blen[l] < (uint32_t)P->cap) continue;
                 if (P->start_only && l > 0 && bd[l - 1] == bd[l] && blen[l - 1] == blen[l] + 1) continue;
+                /* the item's first position has no predecessor in the item: it continues a match from before when
+                 * the byte in front of it repeats at the same distance */
+                if (P->lane0 && l == 0 && p > bd[0] && data[p - 1] == data[p - 1 - bd[0]]) continue;
                 uint32_t maxlen = n - p < 258 ? n - p : 258;
                 uint32_t limit = p < MAXDIST ? p : MAXDIST;
                 if (blen[l] >= maxlen) continue;
@@ -421,7 +483,9 @@ static uint64_t simulate(uint32_t n, const Policy *P, int ctype, uint64_t *walk_
                 int st = 0;
                 uint32_t lastd = 0;
                 int need_cert = 1;
+                int seqn = 0;
                 for (int b = P->deep; b > 0 && c >= 0; --b) {
+                    if (P->seqrule && seqn >= 4) break;
                     if (P->cert && need_cert) {
                         need_cert = 0;
                         ++st;
@@ -431,6 +495,7 @@ static uint64_t simulate(uint32_t n, const Policy *P, int ctype, uint64_t *walk_
                     }
                     uint32_t dist = p - (uint32_t)c;
                     if (dist <= lastd || dist > limit) break;
+                    seqn = dist == lastd + 1 ? seqn + 1 : 0;
                     lastd = dist;
                     ++st;
                     uint32_t bl = blen[l];
@@ -449,6 +514,65 @@ static uint64_t simulate(uint32_t n, const Policy *P, int ctype, uint64_t *walk_
                 }
                 (void)last;
                 if (st > mx) mx = st;
+            }
+            /* tail walk: along the chain of the position t where the four bytes that straddle the end of the best
+             * match start; a candidate there lines up at distance d = t - c, and is measured when the match's head
+             * agrees at that distance */
+            if (P->tailwalk > 0) {
+                int mx2 = 0;
+                for (uint32_t l = 0; l < cnt; ++l) {
+                    uint32_t p = p0 + l;
+                    if (blen[l] < (uint32_t)P->cap) continue;
+                    if (l > 0 && bd[l - 1] == bd[l] && blen[l - 1] == blen[l] + 1 && !(P->maxstart && blen[l - 1] >= 258)) continue;
+                    if (P->tail_lane0 == 0 && l == 0 && p > bd[0] && data[p - 1] == data[p - 1 - bd[0]]) continue;
+                    if (P->tail_maxd && bd[l] > (uint32_t)P->tail_maxd) continue;
+                    uint32_t maxlen = n - p < 258 ? n - p : 258;
+                    uint32_t limit = p < MAXDIST ? p : MAXDIST;
+                    if (blen[l] >= maxlen) continue;
+                    uint32_t t = p + blen[l] - 3;
+                    if (t + 4 > n) continue;
+                    int32_t c = prevp[t];
+                    uint32_t lastd = 0, t_len = blen[l];
+                    int st = 0;
+                    for (int b = P->tailwalk; b > 0; --b) {
+                        uint32_t d = c >= 0 ? t - (uint32_t)c : 0;
+                        if (c < 0 || d <= lastd || d > limit) {
+                            /* this chain is through: the one of the straddle position of the match as it is now */
+                            if (P->tail_restart == 2 && blen[l] > t_len) {
+                                t = p + blen[l] - 3;
+                                t_len = blen[l];
+                                if (t + 4 > n) break;
+                                c = prevp[t];
+                                lastd = 0;
+                                continue;
+                            }
+                            break;
+                        }
+                        lastd = d;
+                        ++st;
+                        if (!memcmp(data + c, data + t, 4) && !memcmp(data + p - d, data + p, 4) &&
+                            data[p + blen[l] - d] == data[p + blen[l]]) {
+                            uint32_t len = mlen(data + p, data + p - d, maxlen);
+                            if (len > blen[l]) {
+                                blen[l] = len;
+                                bd[l] = d;
+                                if (nnew < 64) newd[nnew++] = d;
+                                if (len >= maxlen) break;
+                                if (P->tail_restart == 1) {
+                                    t = p + len - 3;
+                                    t_len = len;
+                                    if (t + 4 > n) break;
+                                    c = prevp[t];
+                                    lastd = 0;
+                                    continue;
+                                }
+                            }
+                        }
+                        c = prevp[c];
+                    }
+                    if (st > mx2) mx2 = st;
+                }
+                steps += (uint64_t)mx2;
             }
             steps += (uint64_t)mx;
             /* share what the deep walks found (later lanes of the same structure) */
@@ -595,7 +719,10 @@ int main(int argc, char **argv) {
     };
     const int ncases = sizeof cases / sizeof cases[0];
     /* policies: name=value pairs on the command line override the defaults below */
-    Policy P = {8, 32, 1, 16, 6, 0, 0, 0, 258, 4096, 0, 0, 1, 0, 0, 32, 4, 0, 0, 0, 0, 0, 0};
+    Policy P;
+    memset(&P, 0, sizeof P);
+    P.chain = 8; P.cap = 32; P.stop_at_cap = 1; P.share_min = 16; P.share_iters = 6; P.lazy = 258; P.min3dist = 4096;
+    P.start_only = 1; P.fan_min = 32; P.fan_stride = 4; P.run_frac = 32; P.seqrule = 1;
     for (int a = 1; a < argc; ++a) {
         char key[32];
         int v;
@@ -603,7 +730,7 @@ int main(int argc, char **argv) {
 #define K(name) if (!strcmp(key, #name)) P.name = v
         K(chain); K(cap); K(stop_at_cap); K(share_min); K(share_iters); K(share_order); K(keep); K(deep);
         K(lazy); K(min3dist); K(dist1); K(exact_own); K(start_only); K(tail_all);
-        K(fan); K(fan_min); K(fan_stride); K(fan_try); K(fan_from0); K(fan_maxd); K(fan_depth); K(itemfast); K(cert);
+        K(fan); K(fan_min); K(fan_stride); K(fan_try); K(fan_from0); K(fan_maxd); K(fan_depth); K(itemfast); K(cert); K(run_stop); K(run_frac); K(run_lag); K(tail_restart); K(maxstart); K(tailwalk); K(tail_lane0); K(tail_maxd); K(seqrule); K(run_same); K(lane0);
 #undef K
     }
     g_dump = getenv("DUMP") != NULL;
@@ -615,13 +742,14 @@ int main(int argc, char **argv) {
         const Case *c = &cases[i];
         if (only && strcmp(only, c->name)) continue;
         uint32_t n = c->n;
+        uint32_t seed = getenv("SEED") ? (uint32_t)strtoul(getenv("SEED"), NULL, 10) : c->seed;
         switch (c->gen) {
-        case 0: zo_gen_random(data, n, c->seed); break;
+        case 0: zo_gen_random(data, n, seed); break;
         case 1: zo_gen_sequential(data, n); break;
-        case 2: zo_gen_random_sequential(data, n, c->seed); break;
-        case 3: zo_gen_text(data, n, c->seed); break;
-        case 4: zo_gen_runs(data, n, c->seed); break;
-        case 5: zo_gen_small_alpha(data, n, c->seed, c->k); break;
+        case 2: zo_gen_random_sequential(data, n, seed); break;
+        case 3: zo_gen_text(data, n, seed); break;
+        case 4: zo_gen_runs(data, n, seed); break;
+        case 5: zo_gen_small_alpha(data, n, seed, c->k); break;
         }
         memset(data + n, 0, 512);
         size_t r1 = zo_rawdeflate(data, n, 1, 0, out, sizeof out, 0);

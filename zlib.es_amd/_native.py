@@ -147,7 +147,7 @@ def set_search(max_chain=DEFAULT_MAX_CHAIN, nice_length=DEFAULT_NICE_LENGTH):
     _check(lib().zgpu_set_search(max_chain, nice_length), "zgpu_set_search")
 
 
-DEFAULT_DEEP_CHAIN, DEFAULT_PROBE_FANS = 0, 1
+DEFAULT_DEEP_CHAIN, DEFAULT_PROBE_FANS = 96, 0
 
 
 def set_long_match(deep_chain=DEFAULT_DEEP_CHAIN, probe_fans=DEFAULT_PROBE_FANS):

@@ -55,9 +55,12 @@ constexpr int HBITS = 13;           // hash-head table entries = 1 << HBITS
 constexpr uint32_t RING = 65536;    // LDS input ring (bytes)
 constexpr uint32_t RING_PAD = 272;  // mirror of ring[0..272) after the end
 constexpr uint32_t WMASK = 0x7fff;  // chain slots (32 Ki positions)
-constexpr int PEND = 2;             // searched items a wave may hold before it must parse the oldest
-constexpr uint32_t LAG = 48;        // an item starts only when all items more than LAG back are parsed
-constexpr uint32_t FAN_MAXDIST = 16;  // probe-ahead fans start from matches at most this far back
+#ifndef ZGPU_LAG_FULL
+#define ZGPU_LAG_FULL 54
+#endif
+constexpr uint32_t LAG = ZGPU_LAG_FULL;  // an item starts only when all items more than LAG back are parsed
+constexpr uint32_t TAIL_MAXDIST = 16;  // tail walks start from matches at most this far back (runs, short periods)
+constexpr int TAIL_STEPS = 8;         // candidates of a tail walk
 #ifndef ZGPU_AHEAD
 #define ZGPU_AHEAD 0
 #endif
@@ -76,9 +79,6 @@ constexpr int SHARE_ITERS_THOROUGH = 16;  // ... and when the walk goes on past 
 // The constants above describe the full-window variant: one 1024-thread workgroup per CU with a
 // 64 KiB ring and 32 Ki chain slots.  SearchCfg gathers what a variant may change; the kernel body
 // reads its geometry from the variant's SearchCfg only.
-#ifndef ZGPU_LAG_FULL
-#define ZGPU_LAG_FULL 48
-#endif
 #ifndef ZGPU_LAG_HALF
 #define ZGPU_LAG_HALF 30
 #endif
@@ -89,6 +89,7 @@ struct CfgFull {  // 32 KiB window, one workgroup per CU
     static constexpr int WG = 1024;
     static constexpr int WG_PER_CU = 1;
     static constexpr uint32_t RING = 65536, CHAIN = 32768, HBITS = 13, NSLOT = 64, NSLOT_E = 128, LAG = ZGPU_LAG_FULL;
+    static constexpr int PEND = 3;
 };
 #ifndef ZGPU_HALF_HBITS
 #define ZGPU_HALF_HBITS 11
@@ -98,12 +99,14 @@ struct CfgHalf {  // units of at most 16 KiB: two workgroups per CU, 16 Ki chain
     static constexpr int WG = 1024;
     static constexpr int WG_PER_CU = ZGPU_HALF_WGS;
     static constexpr uint32_t RING = 32768, CHAIN = 16384, HBITS = ZGPU_HALF_HBITS, NSLOT = 32, NSLOT_E = 64, LAG = ZGPU_LAG_HALF;
+    static constexpr int PEND = 2;  // 64 registers per lane: a third pending item would be paid in spills
 };
 
 struct CfgQuarter {  // units of at most 4 KiB: four workgroups of eight waves per CU, 8 Ki chain slots
     static constexpr int WG = 512;
     static constexpr int WG_PER_CU = 4;
     static constexpr uint32_t RING = 16384, CHAIN = 8192, HBITS = 10, NSLOT = 16, NSLOT_E = 32, LAG = ZGPU_LAG_QUARTER;
+    static constexpr int PEND = 2;
 };
 
 constexpr uint32_t huf_scratch_bytes(uint32_t cap) { return 17 * cap + 128; }  // see HufS
@@ -610,9 +613,9 @@ struct Params {
     uint32_t *counter;          // unit queue head (relative to unit_first)
     uint32_t unit_first, unit_end;
     int lazy, max_chain, nice;
-    int deep, fan;
+    int deep;                   // long-match steps: deep-walk budget (0 = off)
     const uint32_t *unit_list;  // NULL: units unit_first .. unit_end; else list_len unit numbers (and unit_end = ~0)
-    uint32_t list_len;              // long-match steps: deep-walk budget, probe-ahead fans per item (0 = off)
+    uint32_t list_len;
     const uint32_t *unit_prime; // per unit: bytes before it (same stream, multiple of 64, <= 32 KiB) that prime its window
     unsigned long long *prof;   // 16 phase counters (diagnostic builds) or null
 };
@@ -628,6 +631,10 @@ __device__ __forceinline__ void search_units(const Params &P) {
     constexpr int WG = C::WG;
     constexpr uint32_t RING = C::RING, WMASK = C::CHAIN - 1, HBITS = C::HBITS;
     constexpr uint32_t NSLOT = C::NSLOT, NSLOT_E = C::NSLOT_E, LAG = C::LAG;
+    // searched items a wave may hold before it must parse the oldest: the in-order hand-off waits for the slowest
+    // item, and where items differ much in length (deep walks) a wave with room for a third goes on working
+    // (bench with the deep walk on: 83.2 -> 81.9 ms; four are slower again)
+    constexpr int PEND = C::PEND;
     constexpr uint32_t REFILL = RING / 4;  // ring refill granule
     constexpr uint32_t MAXDIST = C::CHAIN - 64 * (LAG + AHEAD) - 128;  // window minus the span of in-flight items
     constexpr uint32_t L_RING = 0, L_PREV = L_RING + RING + RING_PAD, L_HEAD = L_PREV + 2 * C::CHAIN,
@@ -964,7 +971,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
             for (;;) {
                 // A ticket t links item t into the chains and searches item t - AHEAD: the
                 // chains run AHEAD items ahead of the search, so a searched position may follow
-                // the links of the positions up to 256 bytes after it (the probe-ahead step).
+                // the links of the positions up to 256 bytes after it (the long-match steps).
                 uint32_t t = 0;
                 if (lane == 0) t = atomicAdd(&misc[M_ITEM], 1u);
                 t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
@@ -1159,6 +1166,20 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             }
                         }
                     }
+                    // Candidates per walk.  Where three quarters of the item's positions find their nearest candidate
+                    // at the same distance as the position before them, the item lies in long copies (run-like data;
+                    // text has a dozen such positions per item): the parse jumps from long match to long match -- the
+                    // deep walk below sees to their length -- and what the positions in between would find further
+                    // down their chains is hardly ever used.  Three candidates then, instead of max_chain
+                    // (incrementing-run units: sizes +0.1 %).  Only with the deep walk on: without it those positions
+                    // are where the parse lands after a match that was cut short.
+                    int walk_budget = P.max_chain;
+#ifndef ZGPU_NO_RUNLIKE
+                    if (!THOROUGH && !whole && P.deep > 0 && P.max_chain > 3) {
+                        const uint32_t cb = from_below(c, 0xfffffffeu);
+                        if (__builtin_popcountll(__ballot(p + 4 <= n && ((c - cb) & 0xffffu) == 1u)) >= 48) walk_budget = 3;
+                    }
+#endif
                     if (!whole) {
                         // pass 1, lane per position: walk the hash chain.  A candidate costs one
                         // LDS round trip: its chain link and its first 16 bytes (aligned dword
@@ -1168,55 +1189,57 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         // bytes reads 16 more (CMP_CAP; pass 2 finds the exact length of long
                         // matches).
                         const uint32_t cmpmax = maxlen < CMP_CAP ? maxlen : CMP_CAP;
+                        // one candidate of this lane's walk; false: the walk is over
+                        auto candidate = [&]() -> bool {
+                            const uint32_t dist = (p - c) & 0xffffu;
+                            if (dist <= last || dist > limit) {
+                                last = 0xffffu;
+                                return false;
+                            }
+                            last = dist;
+                            const uint32_t ci = c & (RING - 1);
+                            const uint32_t nxt = prevt[c & WMASK];
+                            uint32_t len = mlen16(own, ld16(ring, ci));
+                            if (len == 16 && cmpmax > 16)
+                                len = 16 + mlen16(ld16(ring, pi + 16), ld16(ring, ci + 16));
+                            if (THOROUGH) {
+                                if (len == CMP_CAP) {
+                                    while (len < maxlen) {
+                                        const uint32_t m = mlen16(ld16(ring, (pi + len) & (RING - 1)),
+                                                                  ld16(ring, (ci + len) & (RING - 1)));
+                                        len += m;
+                                        if (m < 16) break;
+                                    }
+                                }
+                                if (len > maxlen) len = maxlen;
+                            } else if (len > cmpmax) {
+                                len = cmpmax;
+                            }
+                            c = nxt;
+                            // selects, not a branch: every branch the wave can diverge on costs a
+                            // handful of scalar instructions per candidate, and the scalar unit is
+                            // shared by all waves of the CU (search kernel 75.3 -> 74.1 ms).  A loop
+                            // with one exit per candidate -- the next link's range test folded into
+                            // it -- was 2 ms slower than this one.
+                            const bool better = len > blen;
+                            blen = better ? len : blen;
+                            best_dist = better ? dist : best_dist;
+                            // as long as the unit allows, or as long as the caller finds nice
+                            // (nice <= CMP_CAP, the default: the first capped candidate ends
+                            // the walk; pass 2 finds its exact length and the long-match
+                            // steps below look for longer ones)
+                            return !(better && (len >= maxlen || len >= (uint32_t)P.nice));
+                        };
                         if (p + 4 <= n) {
                             last = 0;
-                            for (int budget = P.max_chain; budget > 0; --budget) {
+                            for (int budget = walk_budget; budget > 0; --budget) {
                                 // two candidates in and not one position of the item (of those still walking) has
                                 // found four bytes that repeat: incompressible data, whose chains hold hash
                                 // collisions only -- the walk ends for the whole item (random units 56.6 -> 66.6
                                 // GB/s; no named input and none of the bench's kinds changes size; ending after
                                 // one candidate is no faster)
-                                if (!THOROUGH && budget == P.max_chain - 2 && !__ballot(blen >= 4u)) break;
-                                const uint32_t dist = (p - c) & 0xffffu;
-                                if (dist <= last || dist > limit) {
-                                    last = 0xffffu;
-                                    break;
-                                }
-                                last = dist;
-                                const uint32_t ci = c & (RING - 1);
-                                const uint32_t nxt = prevt[c & WMASK];
-                                uint32_t len = mlen16(own, ld16(ring, ci));
-                                if (len == 16 && cmpmax > 16)
-                                    len = 16 + mlen16(ld16(ring, pi + 16), ld16(ring, ci + 16));
-                                if (THOROUGH) {
-                                    if (len == CMP_CAP) {
-                                        while (len < maxlen) {
-                                            const uint32_t m = mlen16(ld16(ring, (pi + len) & (RING - 1)),
-                                                                      ld16(ring, (ci + len) & (RING - 1)));
-                                            len += m;
-                                            if (m < 16) break;
-                                        }
-                                    }
-                                    if (len > maxlen) len = maxlen;
-                                } else if (len > cmpmax) {
-                                    len = cmpmax;
-                                }
-                                c = nxt;
-                                {
-                                    // selects, not a branch: every branch the wave can diverge on costs a
-                                    // handful of scalar instructions per candidate, and the scalar unit is
-                                    // shared by all waves of the CU (search kernel 75.3 -> 74.1 ms).  A loop
-                                    // with one exit per candidate -- the next link's range test folded into
-                                    // it -- was 2 ms slower than this one.
-                                    const bool better = len > blen;
-                                    blen = better ? len : blen;
-                                    best_dist = better ? dist : best_dist;
-                                    // as long as the unit allows, or as long as the caller finds nice
-                                    // (nice <= CMP_CAP, the default: the first capped candidate ends
-                                    // the walk; pass 2 finds its exact length and the long-match
-                                    // steps below look for longer ones)
-                                    if (better && (len >= maxlen || len >= (uint32_t)P.nice)) break;
-                                }
+                                if (!THOROUGH && budget == walk_budget - 2 && !__ballot(blen >= 4u)) break;
+                                if (!candidate()) break;
                             }
                         }
                     }
@@ -1247,8 +1270,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     // better than the nearest long candidate.  The reference looks at every earlier
                     // occurrence and keeps the longest (src/rawdeflate.js:370-395); two bounded
                     // steps go after the same matches here.
-                    const int fans = P.fan;
-                    if ((P.deep > 0 || fans > 0) && __ballot(blen >= CMP_CAP && blen < maxlen)) {
+                    if (P.deep > 0 && __ballot(blen >= CMP_CAP && blen < maxlen)) {
                         // exact length (up to 258) of the match of position px at distance d, px and d
                         // uniform: four bytes per lane, first differing lane by ballot
                         auto coop_len = [&](uint32_t px, uint32_t d, uint32_t mx) -> uint32_t {
@@ -1271,44 +1293,21 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             while (l < mx && ring[(px + l) & (RING - 1)] == ring[(px + l - d) & (RING - 1)]) ++l;
                             return l;
                         };
-                        // the same for up to three distances at once (a zero distance is skipped)
-                        auto coop_len3 = [&](uint32_t px, const uint32_t (&ds)[3], uint32_t mx, uint32_t (&out)[3]) {
-                            const uint32_t q4 = px + ((uint32_t)lane << 2);
-                            const uint32_t *wa = (const uint32_t *)(ring + (q4 & (RING - 1) & ~3u));
-                            const uint32_t a = __builtin_amdgcn_alignbyte(wa[1], wa[0], q4 & 3u);
-                            uint32_t x[3];
-#pragma unroll
-                            for (int i = 0; i < 3; ++i) {
-                                const uint32_t s4 = q4 - ds[i];
-                                const uint32_t *wb = (const uint32_t *)(ring + (s4 & (RING - 1) & ~3u));
-                                x[i] = a ^ __builtin_amdgcn_alignbyte(wb[1], wb[0], s4 & 3u);
-                            }
-                            const uint32_t off = (uint32_t)lane << 2;
-                            const uint32_t left = off < mx ? mx - off : 0u;
-                            const uint32_t pad = left < 4u ? (left ? 0xffffffffu << (left << 3) : 0xffffffffu) : 0u;
-#pragma unroll
-                            for (int i = 0; i < 3; ++i) {
-                                out[i] = 0;
-                                if (!ds[i]) continue;  // uniform
-                                const uint32_t xi = x[i] | pad;
-                                const unsigned long long mm = __ballot(xi != 0u);
-                                if (mm) {
-                                    const uint32_t fl_ = (uint32_t)__builtin_ctzll(mm);
-                                    out[i] = (fl_ << 2) + (rl(ffbl(xi), fl_) >> 3);
-                                } else {
-                                    uint32_t l = 256;
-                                    while (l < mx && ring[(px + l) & (RING - 1)] == ring[(px + l - ds[i]) & (RING - 1)]) ++l;
-                                    out[i] = l;
-                                }
-                            }
-                        };
                         const bool searchable = p + 4 <= n;
+                        // The item's first position has no predecessor in the item; its match continues one from
+                        // before when the byte in front of it repeats at the same distance (inside a long run or
+                        // copy that is every item's first position: without this test each of them walks again
+                        // what the position where the match began has walked already -- a third of all deep-walk
+                        // candidates on incrementing-run data, four fifths on runs of equal bytes).
                         auto starts = [&]() -> unsigned long long {
                             const uint32_t pd = from_below(best_dist, 0u), pl = from_below(blen, 0u);
-                            return __ballot(searchable && blen >= CMP_CAP && blen < maxlen &&
-                                            !(pd == best_dist && pl == blen + 1u));
+                            bool cont = pd == best_dist && pl == blen + 1u;
+                            if (lane == 0 && blen >= CMP_CAP && p > best_dist)
+                                cont = ring[(p - 1u) & (RING - 1)] == ring[(p - 1u - best_dist) & (RING - 1)];
+                            return __ballot(searchable && blen >= CMP_CAP && blen < maxlen && !cont);
                         };
                         if (P.deep > 0) {
+                            bool improved = false;  // this position's match grew in one of the walks below
                             // deep walk: the start lanes go on along their chains; a candidate is
                             // looked at only if the byte after the current best agrees, and then
                             // measured by the whole wave
@@ -1326,20 +1325,32 @@ __device__ __forceinline__ void search_units(const Params &P) {
                                 // usual case where runs and records of different lengths follow each other
                                 // -- then costs two round trips instead of the whole chain.  (A hash
                                 // collision in front of a real occurrence ends a walk too early; that costs
-                                // size, never correctness.)  t's link exists once t's item is linked: the
-                                // same horizon as the probe-ahead step below, waited for the same way.
+                                // size, never correctness.)  t lies up to 255 bytes on, in one of the next four
+                                // items, and its link exists once that item is linked: those items are in other
+                                // waves' hands or are taken by the waves that finish next, and linking an item
+                                // waits for nothing this wave holds, so the wait below ends.  The horizon is a
+                                // function of the item number alone: the output does not depend on timing.
                                 uint32_t horizon = 0xffffffffu;
                                 if constexpr (AHEAD == 0) {
-                                    constexpr uint32_t FAN_ITEMS = WG / 64 < 5 ? WG / 64 : 5;
-                                    const uint32_t hz = k + FAN_ITEMS < blk_end ? k + FAN_ITEMS : blk_end;
+                                    constexpr uint32_t AHEAD_ITEMS = WG / 64 < 5 ? WG / 64 : 5;
+                                    const uint32_t hz = k + AHEAD_ITEMS < blk_end ? k + AHEAD_ITEMS : blk_end;
                                     lds_wait_ge(&misc[M_LINKED], hz);
                                     horizon = hz << 6;
                                 }
+                                PH_END(4);
+                                // The walk itself is a loop of its own per lane with nothing in it but the
+                                // chain: the next link and the candidate's byte where the best match ends,
+                                // requested together (one round trip per candidate), until that byte agrees
+                                // -- a candidate worth measuring -- or the chain, the window or the budget
+                                // ends.  Everything that involves the whole wave (ballots, the measurement,
+                                // the look at t) happens between such stretches, once per improvement and
+                                // not once per candidate: the wave's instructions per candidate, not the
+                                // round trip, were what a deep walk cost.
                                 bool chk = go;
                                 uint32_t tb = ring[(pi + blen) & (RING - 1)];
                                 uint32_t seq = 0;
-                                unsigned long long improved = 0;
-                                for (int budget = P.deep; budget > 0; --budget) {
+                                int budget = P.deep;
+                                for (;;) {
                                     if (__ballot(chk)) {
                                         if (chk) {
                                             const uint32_t t = p + blen - 3u;
@@ -1359,22 +1370,33 @@ __device__ __forceinline__ void search_units(const Params &P) {
                                             chk = false;
                                         }
                                     }
-                                    const uint32_t dist = (p - c) & 0xffffu;
-                                    if (dist <= last || dist > limit) go = false;
-                                    // a chain that runs through consecutive positions is a run of one
-                                    // period: nothing longer further down
-                                    seq = dist == last + 1u ? seq + 1u : 0u;
-                                    if (seq >= 4u) go = false;
-                                    const unsigned long long gm = __ballot(go);
-                                    if (!gm) break;
+                                    PH_END(5);
                                     bool hit = false;
                                     if (go) {
-                                        last = dist;
-                                        const uint32_t cb = ring[(c + blen) & (RING - 1)];
-                                        c = prevt[c & WMASK];
-                                        hit = cb == tb;
+                                        // one exit, and selects instead of branches in the body: the loop
+                                        // compiles to some twenty instructions around its two loads (a lane
+                                        // whose chain has ended loads once more, from addresses masked into
+                                        // range, and ignores the values)
+                                        bool cont;
+                                        do {
+                                            const uint32_t dist = (p - c) & 0xffffu;
+                                            // a chain that runs through consecutive positions is a run of one
+                                            // period: nothing longer further down
+                                            seq = dist == last + 1u ? seq + 1u : 0u;
+                                            const bool ok = dist > last && dist <= limit && seq < 4u && budget > 0;
+                                            const uint32_t cb = ring[(c + blen) & (RING - 1)];
+                                            const uint32_t cn = prevt[c & WMASK];
+                                            --budget;
+                                            hit = ok && cb == tb;
+                                            go = ok;
+                                            last = ok ? dist : last;
+                                            c = ok ? cn : c;
+                                            cont = ok && !hit;
+                                        } while (cont);
                                     }
+                                    PH_END(6);
                                     unsigned long long hm = __ballot(hit);
+                                    if (!hm) break;
                                     while (hm) {
                                         const uint32_t hl = (uint32_t)__builtin_ctzll(hm);
                                         hm &= hm - 1ull;
@@ -1386,13 +1408,90 @@ __device__ __forceinline__ void search_units(const Params &P) {
                                             tb = ring[(pi + blen) & (RING - 1)];
                                             if (len >= maxlen) go = false;
                                             chk = go;
-                                            improved |= 1ull;
+                                            improved = true;
                                         }
                                     }
                                 }
-                                // what the walks found, for the lanes behind them
+                            }
+                            PH_END(2);
+                            // Tail walk.  Where the match repeats at a short distance (a run, a short period) the
+                            // position's own chain is no help: it runs through the run's every position.  The
+                            // chain of t is: it holds the places where the run ended the same way before, each of
+                            // which lines the match up at one distance d = t - candidate; the ones whose head
+                            // agrees there (four bytes, and the byte after the best match) are measured (a hash
+                            // collision on the chain is just one more candidate that fails this test).  The walk
+                            // stays on that chain when the match grows -- the candidates further down line the
+                            // same run end up with other continuations.  Start lanes here are also the item's
+                            // first position and the first one whose match is shorter than the longest possible
+                            // (inside a long run every position continues its predecessor's match, and the last 257
+                            // of them are where a parse that lands there needs the match across the run's end).
+                            // 4-value runs: 1.05-1.08 x the reference's size (FIXED) / 1.00-1.06 x (DYNAMIC) without
+                            // it -> 1.00-1.02 x / 0.96-1.00 x.
+                            {
+                                const uint32_t pd = from_below(best_dist, 0u), pl = from_below(blen, 0u);
+                                bool tgo = searchable && blen >= CMP_CAP && blen < maxlen && best_dist <= TAIL_MAXDIST &&
+                                           !(lane != 0 && pd == best_dist && pl == blen + 1u && pl < 258u);
+                                if (__ballot(tgo)) {
+                                    __builtin_amdgcn_s_setprio(3);
+                                    uint32_t horizon = 0xffffffffu;
+                                    if constexpr (AHEAD == 0) {
+                                        constexpr uint32_t AHEAD_ITEMS = WG / 64 < 5 ? WG / 64 : 5;
+                                        const uint32_t hz = k + AHEAD_ITEMS < blk_end ? k + AHEAD_ITEMS : blk_end;
+                                        lds_wait_ge(&misc[M_LINKED], hz);
+                                        horizon = hz << 6;
+                                    }
+                                    auto ld4 = [&](uint32_t idx) -> uint32_t {  // four bytes at any ring position
+                                        const uint32_t *w = (const uint32_t *)(ring + (idx & (RING - 1) & ~3u));
+                                        return __builtin_amdgcn_alignbyte(w[1], w[0], idx & 3u);
+                                    };
+                                    const uint32_t t = p + blen - 3u;
+                                    tgo = tgo && t + 4u <= n && t < horizon;
+                                    uint32_t tc = prevt[t & WMASK];
+                                    uint32_t tlast = 0;
+                                    uint32_t tb = ring[(pi + blen) & (RING - 1)];
+                                    int budget = TAIL_STEPS;
+                                    for (;;) {
+                                        bool hit = false;
+                                        if (tgo) {
+                                            bool cont;
+                                            do {
+                                                const uint32_t d = (t - tc) & 0xffffu;
+                                                const bool ok = d > tlast && d <= limit && budget > 0;
+                                                // (a lane whose chain has ended loads once more, from addresses
+                                                // masked into range, and ignores the values)
+                                                const uint32_t h4 = ld4(p - d);
+                                                const uint32_t cb = ring[(p + blen - d) & (RING - 1)];
+                                                const uint32_t cn = prevt[tc & WMASK];
+                                                --budget;
+                                                hit = ok && h4 == own.x && cb == tb;
+                                                tgo = ok;
+                                                tlast = ok ? d : tlast;
+                                                tc = ok ? cn : tc;
+                                                cont = ok && !hit;
+                                            } while (cont);
+                                        }
+                                        unsigned long long hm = __ballot(hit);
+                                        if (!hm) break;
+                                        while (hm) {
+                                            const uint32_t hl = (uint32_t)__builtin_ctzll(hm);
+                                            hm &= hm - 1ull;
+                                            const uint32_t px = p0 + hl, d = rl(tlast, hl), mx = rl(maxlen, hl);
+                                            const uint32_t len = coop_len(px, d, mx);
+                                            if ((uint32_t)lane == hl && len > blen) {
+                                                blen = len;
+                                                best_dist = d;
+                                                tb = ring[(pi + blen) & (RING - 1)];
+                                                if (len >= maxlen) tgo = false;
+                                                improved = true;
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                            // what the walks found, for the lanes behind them
+                            if (const unsigned long long im = __ballot(improved)) {
                                 const uint32_t offer = best_dist;
-                                unsigned long long todo = __ballot(improved != 0);
+                                unsigned long long todo = im;
                                 for (int it = 0; it < 4 && todo; ++it) {
                                     const uint32_t d = rl(offer, (uint32_t)__builtin_ctzll(todo));
                                     score_distance(d);
@@ -1402,81 +1501,6 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         }
                         __builtin_amdgcn_s_setprio(1);
                         PH_END(2);
-                        // probe ahead: the positions after a start lane were linked to the nearest
-                        // earlier occurrence of their own four bytes; the distance of such a link,
-                        // tried at the start lane, is a candidate that agrees at least at that
-                        // later place -- the alignments that matter where repeats of different
-                        // lengths follow each other (runs, records)
-                        unsigned long long fanned = 0;
-                        for (int f = 0; f < fans; ++f) {
-                            // only where the match repeats at a short distance (a run, a short period): that
-                            // is where a longer match hides behind thousands of equally near candidates
-                            const unsigned long long sm = starts() & ~fanned & __ballot(best_dist <= FAN_MAXDIST);
-                            if (!sm) break;
-                            // The probes read links of positions up to 256 bytes on: those of the next four
-                            // items of the block.  Without run-ahead linking they are waited for here, by the
-                            // few waves that come this far: the items are in other waves' hands or will be
-                            // taken by the waves that finish next, and linking an item waits for nothing this
-                            // wave holds, so the wait ends.  The horizon is a function of the item number
-                            // alone: the output does not depend on timing.
-                            uint32_t horizon = 0xffffffffu;
-                            if constexpr (AHEAD == 0) {
-                                // as many items on as the workgroup has waves, at most: were all its waves
-                                // waiting here with consecutive items, the oldest must find its items linked
-                                constexpr uint32_t FAN_ITEMS = WG / 64 < 5 ? WG / 64 : 5;
-                                const uint32_t hz = k + FAN_ITEMS < blk_end ? k + FAN_ITEMS : blk_end;
-                                if (f == 0) lds_wait_ge(&misc[M_LINKED], hz);
-                                horizon = hz << 6;
-                            }
-                            const uint32_t sl = (uint32_t)__builtin_ctzll(sm);
-                            fanned |= 1ull << sl;
-                            const uint32_t px = p0 + sl, cur = rl(blen, sl), mx = rl(maxlen, sl), lim = rl(limit, sl);
-                            const uint32_t own4 = rl(own.x, sl);
-                            // lane i probes the link of position px + j, j = cur - 3 + 4 i
-                            const uint32_t j = cur - 3u + ((uint32_t)lane << 2);
-                            const uint32_t q = px + j;
-                            bool ok = j + 4u <= mx && q < horizon;
-                            uint32_t d = 0;
-                            if (ok) {
-                                const uint32_t c2 = prevt[q & WMASK];
-                                d = (q - c2) & 0xffffu;
-                                ok = d >= 1u && d <= lim;
-                                if (ok) {
-                                    // the candidate agrees with px in its first four bytes, and the link
-                                    // is a real repeat of the four bytes at q (not a hash collision)
-                                    const uint32_t h4 = px - d, t4 = q - d;
-                                    const uint32_t *wh = (const uint32_t *)(ring + (h4 & (RING - 1) & ~3u));
-                                    const uint32_t *wt = (const uint32_t *)(ring + (t4 & (RING - 1) & ~3u));
-                                    const uint32_t *wq = (const uint32_t *)(ring + (q & (RING - 1) & ~3u));
-                                    const uint32_t vh = __builtin_amdgcn_alignbyte(wh[1], wh[0], h4 & 3u);
-                                    const uint32_t vt = __builtin_amdgcn_alignbyte(wt[1], wt[0], t4 & 3u);
-                                    const uint32_t vq = __builtin_amdgcn_alignbyte(wq[1], wq[0], q & 3u);
-                                    ok = vh == own4 && vt == vq;
-                                }
-                            }
-                            unsigned long long pm = __ballot(ok);
-                            // up to three distinct distances, the farthest probes first, measured
-                            // side by side (one LDS round trip)
-                            uint32_t dd[3] = {0u, 0u, 0u};
-#pragma unroll
-                            for (int tr = 0; tr < 3; ++tr)
-                                if (pm) {
-                                    dd[tr] = rl(d, 63u - (uint32_t)__builtin_clzll(pm));
-                                    pm &= ~__ballot(d == dd[tr]);
-                                }
-                            uint32_t nb = cur, nd = 0;
-                            if (dd[0]) {
-                                uint32_t ln[3];
-                                coop_len3(px, dd, mx, ln);
-#pragma unroll
-                                for (int tr = 0; tr < 3; ++tr)
-                                    if (dd[tr] && ln[tr] > nb) {
-                                        nb = ln[tr];
-                                        nd = dd[tr];
-                                    }
-                            }
-                            if (nd) score_distance(nd);
-                        }
                         PH_END(3);
                     }
                     if (blen >= 3 && !(blen == 3 && best_dist > 4096)) best_len = blen;

@@ -27,8 +27,7 @@ thread_local int g_last_hip = 0;
 std::atomic<int> g_max_chain{8};
 std::atomic<int> g_nice{32};
 std::atomic<uint64_t> g_split_bytes{1ull << 20};  // units longer than twice this are cut into pieces of at most this size
-std::atomic<int> g_deep{0};        // long-match steps of the search kernel: deep-walk budget ...
-std::atomic<int> g_fan{1};         // ... and probe-ahead fans per item
+std::atomic<int> g_deep{96};       // long-match steps of the search kernel: deep-walk budget (0 = off)
 std::atomic<int> g_min_lazy{258};  // the parse always looks one position ahead unless told otherwise
 std::atomic<int> g_live{0};        // plans and jobs alive: zgpu_shutdown leaves the device state alone while any is
 unsigned long long *g_prof = nullptr;  // diagnostic builds only
@@ -287,11 +286,11 @@ void free_ck_scratch(CkScratch *c) {
 
 // the engine knobs as one plan sees them (read once, when the plan is set up)
 struct Knobs {
-    int max_chain, nice, deep, fan, min_lazy;
+    int max_chain, nice, deep, min_lazy;
     uint64_t split;
 };
 Knobs read_knobs() {
-    return Knobs{g_max_chain.load(), g_nice.load(), g_deep.load(), g_fan.load(), g_min_lazy.load(), g_split_bytes.load()};
+    return Knobs{g_max_chain.load(), g_nice.load(), g_deep.load(), g_min_lazy.load(), g_split_bytes.load()};
 }
 
 }  // namespace
@@ -1113,8 +1112,7 @@ int zgpu_set_search(int max_chain, int nice_length) {
 
 int zgpu_set_long_match(int deep_chain, int probe_fans) {
     if (deep_chain < 0 || deep_chain > 32768 || probe_fans < 0 || probe_fans > 64) return ZGPU_E_ARG;
-    g_deep = deep_chain;
-    g_fan = probe_fans;
+    g_deep = deep_chain;  // probe_fans: accepted, no longer used (see zgpu.h)
     return ZGPU_OK;
 }
 
@@ -1203,7 +1201,6 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             P.max_chain = p->knobs.max_chain;
             P.nice = p->knobs.nice;
             P.deep = p->knobs.deep;
-            P.fan = p->knobs.fan;
             P.unit_prime = p->d_prime;
             P.prof = g_prof;
             // one launch over the round's range, or one per size class over its list
