@@ -158,7 +158,6 @@ def main():
     ap.add_argument("--chain", type=int, default=0, help="hash-chain search depth (0 = library default)")
     ap.add_argument("--nice", type=int, default=32)
     ap.add_argument("--deep", type=int, default=-1, help="long-match deep-walk budget (-1 = library default)")
-    ap.add_argument("--fan", type=int, default=-1, help="probe-ahead fans per 64 bytes (-1 = library default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,11 +165,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path to time)")
-    # one rank per GPU; ZGPU_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with
-    # fewer GPUs than ranks (ranks then share devices and the reductions run on the CPU)
-    backend = os.environ.get("ZGPU_BENCH_BACKEND", "nccl")
+    # One rank per GPU.  The ranks exchange no data (units are independent): the process group carries
+    # the barriers and two scalar reductions of the timing, which run over gloo on the CPU -- RCCL is
+    # not part of this path.  ZGPU_BENCH_SHARE_GPUS=1 rehearses the multi-rank flow on a box with
+    # fewer GPUs than ranks (ranks then share devices).
     ndev = torch.cuda.device_count()
-    if backend == "nccl" and local_rank >= ndev:
+    if local_rank >= ndev and os.environ.get("ZGPU_BENCH_SHARE_GPUS") != "1":
         raise SystemExit("rank %d has no GPU of its own (%d visible)" % (local_rank, ndev))
     local_dev = local_rank % ndev
     torch.cuda.set_device(local_dev)
@@ -179,19 +179,15 @@ def main():
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    red_dev = dev if backend == "nccl" else torch.device("cpu")
+        dist.init_process_group("gloo")
+    red_dev = torch.device("cpu")
 
     import zlib_es_amd as z
     N = z._native
     if args.chain or args.nice != 32:
         z.set_search(args.chain or z._native.DEFAULT_MAX_CHAIN, args.nice)
-    if args.deep >= 0 or args.fan >= 0:
-        N.set_long_match(args.deep if args.deep >= 0 else N.DEFAULT_DEEP_CHAIN,
-                         args.fan if args.fan >= 0 else N.DEFAULT_PROBE_FANS)
+    if args.deep >= 0:
+        N.set_long_match(args.deep)
 
     def barrier():
         torch.cuda.synchronize()
@@ -206,15 +202,33 @@ def main():
         res = bench_deflate(ctx, args.workload)
         if rank == 0 and world == 1 and args.workload == "deflate" and not args.no_extras:
             # the other configurations and the drop-in path, in short form, with the same line shape
-            for name in ("zip", "gzip"):
+            legs = {"zip": lambda: brief(bench_deflate(ctx, "zip", short=True)),
+                    "gzip": lambda: brief(bench_deflate(ctx, "gzip", short=True)),
+                    # the same 65536 x 64 KiB batch under FIXED coding (BASELINE config 3 names both modes)
+                    "fixed": lambda: brief(bench_deflate(ctx, "deflate", short=True, ctype=1)),
+                    # BASELINE config 2: CRC-32 + Adler-32 over 4 GiB
+                    "checksum": lambda: brief(bench_checksum(ctx, short=True))}
+            for name, leg in legs.items():
                 try:
-                    res.setdefault("other_workloads", {})[name] = brief(bench_deflate(ctx, name, short=True))
+                    res.setdefault("other_workloads", {})[name] = leg()
                 except Exception as e:  # noqa: BLE001  (a secondary leg must not cost the headline line)
                     res.setdefault("other_workloads", {})[name] = {"error": repr(e)}
+                torch.cuda.empty_cache()
             try:
                 res["end_to_end"] = end_to_end(ctx)
             except Exception as e:  # noqa: BLE001
                 res["end_to_end"] = {"error": repr(e)}
+    if args.workload == "deflate" and world > 1 and not args.no_extras:
+        # The path a Node process takes on a multi-GPU host: ONE process, host buffers, the batch split over
+        # the devices named in zgpu_init.  Rank 0 runs it over all the node's GPUs while the other ranks wait
+        # (their GPUs are idle by then); reported beside the per-rank figure, never as `value`.
+        barrier()
+        if rank == 0:
+            try:
+                res["in_process_host_path"] = host_multi_device(ctx, list(range(min(world, ndev))))
+            except Exception as e:  # noqa: BLE001
+                res["in_process_host_path"] = {"error": repr(e)}
+        barrier()
     if rank == 0:
         print(json.dumps(res), flush=True)
     barrier()
@@ -224,7 +238,8 @@ def main():
 
 def brief(r):
     keep = ("value", "unit", "ms_per_step", "config", "ratio_out_over_in", "roofline", "roundtrip_all_units",
-            "units_verified_on_gpu", "units_failed", "ratio_vs_ref", "cpu_baseline", "crc_checked")
+            "units_verified_on_gpu", "units_failed", "ratio_vs_ref", "ratio_vs_ref_by_kind", "cpu_baseline", "crc_checked",
+            "bit_exact")
     return {k: r[k] for k in keep if k in r}
 
 
@@ -282,8 +297,11 @@ def make_workload(ctx, workload, short):
     raise ValueError(workload)
 
 
-def bench_deflate(ctx, workload, short=False):
+def bench_deflate(ctx, workload, short=False, ctype=None):
     args, z, N, dev, rank, world, dist = (ctx[k] for k in ("args", "z", "N", "dev", "rank", "world", "dist"))
+    if ctype is not None:  # a secondary leg under another compressionType
+        args = argparse.Namespace(**dict(vars(args), ctype=ctype))
+        ctx = dict(ctx, args=args)
     barrier, red_dev = ctx["barrier"], ctx["red_dev"]
     steps, warmup = (2, 1) if short else (args.steps, args.warmup)
     data, groups, desc, cfg = make_workload(ctx, workload, short)
@@ -332,8 +350,7 @@ def bench_deflate(ctx, workload, short=False):
     cfg["workload"] = desc
     cfg["parallelism"] = "units sharded over %d GPU(s), no collective" % world
     cfg["search"] = {"max_chain": args.chain or N.DEFAULT_MAX_CHAIN, "nice_length": args.nice,
-                     "deep_chain": args.deep if args.deep >= 0 else N.DEFAULT_DEEP_CHAIN,
-                     "probe_fans": args.fan if args.fan >= 0 else N.DEFAULT_PROBE_FANS}
+                     "deep_chain": args.deep if args.deep >= 0 else N.DEFAULT_DEEP_CHAIN}
     res = {
         "metric": METRIC if workload == "deflate" else "deflate input GB/s (%s workload)" % workload,
         "value": round(value, 3), "unit": "GB/s", "n_gpus": world,
@@ -367,7 +384,8 @@ def bench_deflate(ctx, workload, short=False):
         if workload == "gzip":
             res.update(check_stream_crc(ctx, data, groups, fetched))
         if world == 1 and not args.no_cpu:
-            res.update(cpu_leg(args, data, groups, outs, fetched, 4.0 if short else args.cpu_seconds))
+            res.update(cpu_leg(args, data, groups, outs, fetched, 4.0 if short else args.cpu_seconds,
+                               kind_of=unit_kind if workload == "deflate" else None))
     for p in plans:
         p.close()
     return res
@@ -441,15 +459,28 @@ def check_stream_crc(ctx, data, groups, fetched):
     return {"crc_checked": bool(ok)}
 
 
-def cpu_leg(args, data, groups, outs, fetched, seconds):
+KIND_NAMES = ("text", "incrementing runs", "random", "low entropy")
+
+
+def unit_kind(u):
+    """content kind of unit u of gen_units (index into KIND_NAMES)"""
+    k = u % 20
+    return 0 if k < 10 else 1 if k < 15 else 2 if k < 18 else 3
+
+
+def cpu_leg(args, data, groups, outs, fetched, seconds, kind_of=None):
     """Oracle on a bounded sample of the same units: baseline speed (one thread, then every
-    core of the box's share over disjoint units), size ratio, round trip."""
+    core of the box's share over disjoint units), size ratio -- in total and, where the batch's
+    layout tells the content kind of a unit (kind_of), per kind -- and round trip."""
+    import math
     import _oracle as zo
     zo.lib()
     sample = []
     for (off, ctype, flags, _), out, (out_off, _) in zip(groups, outs, fetched):
         n = off.size - 1
         stride = max(1, n // (2048 // len(groups)))
+        while kind_of is not None and stride > 1 and math.gcd(stride, 20) != 1:
+            stride += 1  # the kinds repeat every 20 units: a stride that shares a factor with 20 would skip some
         for u in range(0, n, stride):
             sample.append((off, out, out_off, u, ctype, bool(flags & 1)))
     host = {}
@@ -463,6 +494,7 @@ def cpu_leg(args, data, groups, outs, fetched, seconds):
 
     # one thread
     t_used, n_done, ref_bytes, gpu_bytes, in_b, ok = 0.0, 0, 0, 0, 0, True
+    by_kind = [[0, 0, 0] for _ in KIND_NAMES]  # units, reference bytes, GPU bytes
     for i in range(len(sample)):
         if t_used > seconds * 0.5:
             break
@@ -475,6 +507,9 @@ def cpu_leg(args, data, groups, outs, fetched, seconds):
             ok = ok and zo.inflate_raw(comp, unit.size) == unit.tobytes()
         ref_bytes += len(ref)
         gpu_bytes += comp.size
+        if kind_of is not None:
+            row = by_kind[kind_of(sample[i][3])]
+            row[0], row[1], row[2] = row[0] + 1, row[1] + len(ref), row[2] + comp.size
         in_b += unit.size
         n_done += 1
     one = in_b / max(t_used, 1e-9) / 1e9
@@ -504,7 +539,14 @@ def cpu_leg(args, data, groups, outs, fetched, seconds):
         done_bytes = sum(ex.map(work, packs))
     t_all = time.perf_counter() - t0
     all_rate = done_bytes / t_all / 1e9
+    extra = {}
+    if kind_of is not None:
+        # the summed ratio weighs every kind by its compressed bytes (incrementing runs and low-entropy units
+        # compress to 1-3 %): each kind against the reference on its own units
+        extra["ratio_vs_ref_by_kind"] = {KIND_NAMES[k]: {"ratio": round(g / max(r, 1), 5), "units": c}
+                                         for k, (c, r, g) in enumerate(by_kind) if c}
     return {
+        **extra,
         "cpu_baseline": {"value": round(all_rate, 5), "unit": "GB/s", "cores": nth, "kind": "port",
                          "single_core_value": round(one, 5), "cpu_model": cpu_model(),
                          "sample": "%d of the same units (evenly spaced over the batch), C restatement of "
@@ -548,9 +590,9 @@ def end_to_end(ctx):
     return res
 
 
-def bench_checksum(ctx):
+def bench_checksum(ctx, short=False):
     args, z, dev, rank, world, barrier = (ctx[k] for k in ("args", "z", "dev", "rank", "world", "barrier"))
-    nbytes = (args.units or 65536) * (args.unit_bytes or 65536)
+    nbytes = (65536 * 65536) if short else (args.units or 65536) * (args.unit_bytes or 65536)
     g = torch.Generator(device=dev)
     g.manual_seed(99 + rank)
     data = torch.randint(0, 256, (nbytes,), device=dev, generator=g, dtype=torch.uint8)
@@ -576,7 +618,7 @@ def bench_checksum(ctx):
                         "kernel_ms": round(k_ms, 3)}}
     if rank == 0 and world == 1 and not args.no_cpu:
         import _oracle as zo
-        n = min(nbytes, 256 << 20)
+        n = min(nbytes, (64 << 20) if short else (256 << 20))
         host = data[:n].cpu().numpy()
         t0 = time.perf_counter()
         c, a = zo.crc32(host), zo.adler32(host)

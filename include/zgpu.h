@@ -79,8 +79,10 @@ enum {
  * device is current).  A host-buffer batch (zgpu_deflate_batch*) of 128 MiB and
  * more is shared by the named devices: its units are split into contiguous
  * ranges of about equal input bytes, one range per device (one more device per
- * 64 MiB of input), every device runs its range through its own streams from
- * its own host threads, and the host concatenates the results in unit order --
+ * 128 MiB of input -- two full sub-batches, so ZGPU_SUB_BYTES moves the figure), every
+ * device runs its range through its own streams from its own host threads (bound
+ * to the CPUs the system lists as local to that GPU, ZGPU_NO_AFFINITY=1 leaves
+ * them unbound), and the host concatenates the results in unit order --
  * no collective, the ranges are independent (what Zip.compress()'s per-file
  * loop, src/zip.js:119-137, and the chunks of a long stream, src/gzip.js:107-111,
  * allow).  Smaller calls run on the current device if it is among the named
@@ -88,6 +90,8 @@ enum {
  * Optional: every entry point initialises lazily.  Device-pointer entry points
  * (zgpu_plan_*, zgpu_checksum_device*) always use the current device. */
 int zgpu_init(const int *device_ids, int n_devices);
+/* An id outside 0 .. zgpu_device_count() - 1 returns ZGPU_E_ARG and leaves the
+ * list that was in force untouched. */
 /* Number of visible devices (what zgpu_init's ids index), or a negative error. */
 int zgpu_device_count(void);
 /* Releases the per-device state (tables, staging buffers, streams).  Does
@@ -166,7 +170,7 @@ uint64_t zgpu_deflate_bound(uint64_t in_len);
  * dynamicHuffman :243-259, BitStream src/bitstream.js:42-95) for n_units
  * independent inputs in one call; it is also what Zip.compress()'s per-file
  * loop (src/zip.js:119-137) turns into.  in/out are host pointers; the call
- * blocks until done.  The batch moves in sub-batches of about 32 MiB through
+ * blocks until done.  The batch moves in sub-batches of 8 to 64 MiB through
  * four stream slots per device, so uploads, kernels and downloads overlap;
  * the slots' device buffers and workspaces are kept from call to call (a
  * steady caller allocates nothing after its first calls).
@@ -202,6 +206,24 @@ int zgpu_deflate_batch_finish(zgpu_job *job, uint8_t *out, uint64_t out_cap, uin
 int zgpu_deflate_batch_finish_spaced(zgpu_job *job, uint8_t *out, uint64_t out_cap, const uint32_t *gap,
                                      uint64_t *out_pos, uint32_t *crc32, uint32_t *adler32);
 void zgpu_job_release(zgpu_job *job);
+
+/* ---- page-locked host memory for the host-buffer entry points --------------
+ * No counterpart in the reference (its buffers are JS typed arrays).  The
+ * host-buffer calls take any host pointer; from ordinary (pageable) memory the
+ * HIP runtime moves the bytes through its own staging at about half the PCIe
+ * rate.  Input and output buffers obtained here are page-locked and visible to
+ * every device, so uploads and downloads are direct DMA: the entry points need
+ * no hint, the runtime recognises the pointers.  The N-API addon hands such
+ * memory to JavaScript as an external ArrayBuffer (allocInput).
+ * zgpu_host_alloc returns NULL when the memory cannot be had.
+ * Footprint of the library itself: every device keeps, between two-step calls
+ * (zgpu_deflate_batch_begin / _finish), a page-locked staging buffer of the
+ * largest result it has held, up to 1.5 GiB (ZGPU_SPARE_HOST_BYTES); larger
+ * ones live only as long as their job.  zgpu_host_trim releases those spares
+ * and the spare device result buffers now (the next call allocates again). */
+void *zgpu_host_alloc(uint64_t bytes);
+void zgpu_host_free(void *p);
+void zgpu_host_trim(void);
 
 /* ---- RawDeflate, device-resident plan ------------------------------------
  * Same operation with inputs and outputs resident in HBM.  A plan holds the

@@ -219,3 +219,15 @@ def test_zip_compress_with_password(z):
                        "deflateOption": {"compressionType": 1}})
     got = _read_encrypted(bytes(zp.compress()), each)
     assert got == {name: d.tobytes() for name, d in datas.items()}
+
+
+def test_zip_password_as_a_byte_array(z):
+    # the reference's passwords are Uint8Arrays (src/zip.js:95,287-294); their Python counterpart is a numpy array
+    d = zo.gen({"gen": "text", "n": 12000, "seed": 8})
+    pw_archive, pw_file = np.arange(9, dtype=np.uint8) + 3, np.array([200, 1, 2, 3], dtype=np.uint8)
+    zp = z.Zip()
+    zp.setPassword(pw_archive)
+    zp.addFile(d, {"filename": b"whole", "date": (2020, 1, 2, 3, 4, 6)})
+    zp.addFile(d[:5000], {"filename": b"own", "password": pw_file, "date": (2020, 1, 2, 3, 4, 6)})
+    got = _read_encrypted(bytes(zp.compress()), {"whole": pw_archive.tolist(), "own": pw_file.tolist()})
+    assert got == {"whole": d.tobytes(), "own": d[:5000].tobytes()}

@@ -26,7 +26,7 @@ SYMBOLS = [
     "zgpu_plan_adler_device", "zgpu_plan_fetch", "zgpu_plan_kernel_ms", "zgpu_plan_phase_ms", "zgpu_checksum",
     "zgpu_checksum_device", "zgpu_noalloc_setup", "zgpu_noalloc_max_bytes",
     "zgpu_checksum_device_noalloc", "zgpu_crc32_update", "zgpu_adler32_update", "zgpu_checksum_kernel_ms",
-    "zgpu_crc32_combine", "zgpu_adler32_combine",
+    "zgpu_crc32_combine", "zgpu_adler32_combine", "zgpu_host_alloc", "zgpu_host_free", "zgpu_host_trim",
 ]
 
 _lib = None
@@ -119,6 +119,12 @@ def lib():
     L.zgpu_crc32_combine.argtypes = [u32, u32, u64]
     L.zgpu_adler32_combine.restype = u32
     L.zgpu_adler32_combine.argtypes = [u32, u32, u64]
+    L.zgpu_host_alloc.restype = vp
+    L.zgpu_host_alloc.argtypes = [u64]
+    L.zgpu_host_free.restype = None
+    L.zgpu_host_free.argtypes = [vp]
+    L.zgpu_host_trim.restype = None
+    L.zgpu_host_trim.argtypes = []
     _lib = L
     return L
 
@@ -153,6 +159,36 @@ DEFAULT_DEEP_CHAIN, DEFAULT_PROBE_FANS = 96, 0
 def set_long_match(deep_chain=DEFAULT_DEEP_CHAIN, probe_fans=DEFAULT_PROBE_FANS):
     """Bounds of the search kernel's long-match steps; without arguments back to the defaults."""
     _check(lib().zgpu_set_long_match(deep_chain, probe_fans), "zgpu_set_long_match")
+
+
+class HostBuffer:
+    """Page-locked host memory from zgpu_host_alloc as a numpy uint8 array (`.array`): input and output
+    buffers of the host-buffer entry points that move at the full PCIe rate.  `close()` frees it; views
+    of `.array` must not be used after that."""
+
+    def __init__(self, nbytes):
+        self.ptr = lib().zgpu_host_alloc(int(nbytes))
+        if not self.ptr:
+            raise ZgpuError(-3, "zgpu_host_alloc(%d)" % nbytes)  # ZGPU_E_NOMEM
+        self.nbytes = int(nbytes)
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(1, self.nbytes)).from_address(self.ptr))[: self.nbytes]
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            lib().zgpu_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+def host_trim():
+    """Releases the spare staging buffers the devices keep between host-buffer calls."""
+    lib().zgpu_host_trim()
 
 
 def set_split(piece_bytes):

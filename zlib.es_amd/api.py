@@ -187,7 +187,9 @@ class Deflate:
         self.rawDeflate.op = 2
         self.rawDeflate._want = 2  # Adler-32 of the input (:83) from the same call
         body = self.rawDeflate.compress()  # :84-85
-        adler = self.rawDeflate._adler32
+        adler = getattr(self.rawDeflate, "_adler32", None)
+        if adler is None:  # a RawDeflate whose block makers were replaced: a checksum pass of its own (:83)
+            adler = Adler32.mkHash(self.input)
         trailer = np.array([(adler >> 24) & 0xFF, (adler >> 16) & 0xFF, (adler >> 8) & 0xFF, adler & 0xFF],
                            dtype=np.uint8)  # :94-97
         self.output = np.concatenate([body, trailer])
@@ -268,7 +270,9 @@ class Gzip:
         rawdeflate = RawDeflate(self.input, opts)  # :107-111
         rawdeflate._want = 1  # CRC-32 of the input (:117) from the same call
         body = rawdeflate.compress()
-        crc32 = rawdeflate._crc32
+        crc32 = getattr(rawdeflate, "_crc32", None)
+        if crc32 is None:
+            crc32 = CRC32.calc(self.input)  # :117
         il = self.input.size & 0xFFFFFFFF
         tr = np.array([crc32 & 0xFF, (crc32 >> 8) & 0xFF, (crc32 >> 16) & 0xFF, (crc32 >> 24) & 0xFF,
                        il & 0xFF, (il >> 8) & 0xFF, (il >> 16) & 0xFF, (il >> 24) & 0xFF], dtype=np.uint8)
@@ -402,7 +406,8 @@ class Zip:
                 # fills the header from Math.random() and tests the FILE index against 11 where the
                 # format puts a CRC byte into header byte 11; mirrored as it is (its own Unzip does not
                 # look at that byte).
-                key = self.createEncryptionKey(opt.get("password") or self.password)
+                pw = opt.get("password")
+                key = self.createEncryptionKey(self.password if pw is None else pw)  # (a numpy array has no truth value)
                 plain = f["buffer"]
                 enc = np.empty(plain.size + 12, dtype=np.uint8)
                 for j in range(12):
@@ -440,7 +445,9 @@ class Zip:
                 Y, Mo, D, h, mi, s = date.tm_year, date.tm_mon, date.tm_mday, date.tm_hour, date.tm_min, date.tm_sec
             crc, size, plain = f["crc32"], f["buffer"].size, f["size"]
             method = opt["compressionMethod"]
-            flags = Zip.Flags.ENCRYPT if (opt.get("password") or self.password) else 0  # :177-180
+            pw = opt.get("password")
+            pw = self.password if pw is None else pw
+            flags = Zip.Flags.ENCRYPT if (pw is not None and len(pw) > 0) else 0  # :177-180
             common = [need & 0xFF, (need >> 8) & 0xFF, flags & 0xFF, (flags >> 8) & 0xFF, method & 0xFF, (method >> 8) & 0xFF,
                       (((mi & 0x7) << 5) | (s // 2)) & 0xFF, ((h << 3) | (mi >> 3)) & 0xFF,
                       ((((Mo) & 0x7) << 5) | D) & 0xFF, ((((Y - 1980) & 0x7F) << 1) | (Mo >> 3)) & 0xFF,

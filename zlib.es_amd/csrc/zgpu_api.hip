@@ -3,9 +3,15 @@
 // compression or checksum path exists here: without a GPU every entry point
 // returns ZGPU_E_NODEVICE.
 #include <hip/hip_runtime.h>
+#include <ctype.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#if defined(__linux__)
+#include <pthread.h>
+#include <sched.h>
+#endif
 #include <atomic>
 #include <condition_variable>
 #include <memory>
@@ -694,7 +700,7 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
 }
 
 // ---- host-buffer entry points: per-device staging kept from call to call ----------------
-// A batch in host memory is cut into sub-batches of about kSubBytes of input (32 MiB).  Four slots per
+// A batch in host memory is cut into sub-batches of at most kSubBytes of input (64 MiB).  Four slots per
 // device (stream, input buffer, plan with its workspace) take them in turn, each driven by its
 // own host thread: the upload of one sub-batch runs while another is compressed and a third is
 // fetched, so PCIe and the kernels overlap.  Nothing here is allocated per call once the
@@ -704,13 +710,24 @@ constexpr int kMaxSlots = 8;
 const uint64_t kSubBytes = [] {
     const char *e = getenv("ZGPU_SUB_BYTES");
     const uint64_t v = e ? strtoull(e, nullptr, 10) : 0;
-    return v >= (1ull << 20) ? v : (32ull << 20);
+    return v >= (1ull << 20) ? v : (64ull << 20);
 }();
 constexpr uint64_t kStageMaxBytes = 3ull << 30;
+// the page-locked staging buffer a device keeps between two-step calls is at most this large
+// (ZGPU_SPARE_HOST_BYTES overrides; larger ones are released when their job ends)
+const uint64_t kSpareHostBytes = [] {
+    const char *e = getenv("ZGPU_SPARE_HOST_BYTES");
+    return e ? strtoull(e, nullptr, 10) : (1536ull << 20);
+}();
 const int kSlots = [] {
     const char *e = getenv("ZGPU_SLOTS");
     const int v = e ? atoi(e) : 0;
     return v >= 2 && v <= kMaxSlots ? v : 4;
+}();
+const int kComputeGate = [] {
+    const char *e = getenv("ZGPU_COMPUTE_GATE");
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= kMaxSlots ? v : 2;
 }();
 struct Slot {
     hipStream_t st = nullptr;
@@ -718,8 +735,56 @@ struct Slot {
     zgpu_plan *plan = nullptr;
     DevBuf ck_off, ck_crc, ck_adler;  // segment tables of the host checksum call
 };
+// a counting gate for the stages of the host pipeline
+struct Gate {
+    std::mutex mu;
+    std::condition_variable cv;
+    int free_;
+    explicit Gate(int n) : free_(n) {}
+    void enter() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return free_ > 0; });
+        --free_;
+    }
+    void leave() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            ++free_;
+        }
+        cv.notify_one();
+    }
+};
+struct GateHold {
+    Gate *g;
+    explicit GateHold(Gate &g_, bool use = true) : g(use ? &g_ : nullptr) {
+        if (g) g->enter();
+    }
+    ~GateHold() {
+        if (g) g->leave();
+    }
+};
+// whether a host pointer lies in page-locked memory (hipHostMalloc / hipHostRegister, zgpu_host_alloc)
+bool is_page_locked(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // ordinary memory is reported as an error: not one of ours
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
 struct HostCtx {
     std::mutex mu;  // one host-buffer call at a time per device
+    // The slots' threads take turns at the three resources a sub-batch needs one after the other: the link to the
+    // device, the compute units, the link back.  Left to themselves the threads fall into step -- all upload at
+    // once, each at a quarter of the rate, then all compute, then all download: the phases follow each other
+    // instead of overlapping (a trace of 1 GiB: 22 ms of kernels inside a 40 ms call).  One upload and one
+    // download at a time, and two sub-batches' kernels (the second fills the compute units the first leaves idle
+    // at its end), make it a pipeline.
+    // (Only for page-locked buffers, which move by DMA at the link's rate: from ordinary memory the runtime
+    // copies through its own staging on the calling thread, and there several threads side by side are what
+    // reaches the link's rate -- those calls pass the upload / download gates without waiting.)
+    Gate up{1}, compute{kComputeGate}, down{1};
     Slot slot[kMaxSlots];
     DevBuf d_res;   // compressed bytes of a batch until they are copied out (spare; a job takes it)
     HostBuf h_res;  // ... and their page-locked landing place on the host for two-step calls
@@ -826,6 +891,7 @@ struct BatchShared {
     // sizes of all sub-batches before it are known
     uint8_t *out = nullptr;
     uint64_t out_cap = 0;
+    bool in_locked = false, out_locked = false;  // the caller's buffers are page-locked
     std::mutex mu;
     std::condition_variable cv;
     size_t placed = 0;       // sub-batches [0, placed) have their sizes in
@@ -854,22 +920,31 @@ int run_sub(BatchShared &S, size_t si, Slot &sl) {
     for (uint32_t i = 0; i <= n; ++i) rel[i] = go[i] - lo + lead;
     uint32_t flags = S.flags;
     if (sb.end != S.n_units) flags &= ~(uint32_t)ZGPU_F_FINAL_LAST;
-    int rc = plan_setup(sl.plan, rel.data(), n, S.ctype, S.lazy, flags, hist, sl.st, true);
-    if (rc) return rc;
+    int rc = ZGPU_OK;
     if ((rc = sl.d_in.ensure(lead + (hi - lo) + 64)) != ZGPU_OK) return rc;
-    if (hi > lo) HIPCHK(hipMemcpyAsync(sl.d_in.as<uint8_t>() + lead, S.in + lo, hi - lo, hipMemcpyHostToDevice, sl.st));
+    {
+        GateHold up(dv.ctx->up, S.in_locked);
+        rc = plan_setup(sl.plan, rel.data(), n, S.ctype, S.lazy, flags, hist, sl.st, true);
+        if (rc) return rc;
+        if (hi > lo) HIPCHK(hipMemcpyAsync(sl.d_in.as<uint8_t>() + lead, S.in + lo, hi - lo, hipMemcpyHostToDevice, sl.st));
+        HIPCHK(hipStreamSynchronize(sl.st));
+    }
     uint8_t *d_out = dv.d_res.as<uint8_t>() + sb.res_off;
-    rc = zgpu_plan_run(sl.plan, sl.d_in.p, d_out, sb.res_cap, sl.st);
-    if (rc) return rc;
     // offsets relative to this sub-batch's result region; the n + 1 entries go through a local
     // array because entry n would land on the next sub-batch's first
     std::vector<uint64_t> loc((size_t)n + 1);
-    rc = zgpu_plan_fetch(sl.plan, loc.data(), j->crc.empty() ? nullptr : j->crc.data() + sb.first,
-                         j->adler.empty() ? nullptr : j->adler.data() + sb.first, sl.st);
-    if (rc) return rc;
+    {
+        GateHold compute(dv.ctx->compute);
+        rc = zgpu_plan_run(sl.plan, sl.d_in.p, d_out, sb.res_cap, sl.st);
+        if (rc) return rc;
+        rc = zgpu_plan_fetch(sl.plan, loc.data(), j->crc.empty() ? nullptr : j->crc.data() + sb.first,
+                             j->adler.empty() ? nullptr : j->adler.data() + sb.first, sl.st);
+        if (rc) return rc;
+    }
     memcpy(j->out_off.data() + sb.first, loc.data(), (size_t)n * sizeof(uint64_t));
     sb.out_bytes = loc[n];
     if (dv.staged && sb.out_bytes) {
+        GateHold down(dv.ctx->down);  // the library's own staging is page-locked
         HIPCHK(hipMemcpyAsync((uint8_t *)dv.h_res.p + sb.res_off, d_out, sb.out_bytes, hipMemcpyDeviceToHost, sl.st));
         HIPCHK(hipStreamSynchronize(sl.st));
     }
@@ -886,6 +961,7 @@ int run_sub(BatchShared &S, size_t si, Slot &sl) {
     S.cv.notify_all();
     if (at + sb.out_bytes > S.out_cap) return ZGPU_E_OUTCAP;
     if (sb.out_bytes) {
+        GateHold down(dv.ctx->down, S.out_locked);
         HIPCHK(hipMemcpyAsync(S.out + at, d_out, sb.out_bytes, hipMemcpyDeviceToHost, sl.st));
         HIPCHK(hipStreamSynchronize(sl.st));
     }
@@ -900,6 +976,72 @@ void fail_shared(BatchShared &S, int rc) {
     S.cv.notify_all();
 }
 
+// The CPUs the system lists as local to a GPU (/sys/bus/pci/devices/<bus id>/local_cpulist), cut down to
+// the ones this process may run on.  A device's host threads are bound to them: their copies to and from
+// page-locked buffers and their launches then stay on the GPU's own socket.  Empty when the file cannot be
+// read, names no CPU this process may use, or ZGPU_NO_AFFINITY=1.
+#if defined(__linux__)
+bool device_cpus(int device, cpu_set_t *out) {
+    static const bool off = [] {
+        const char *e = getenv("ZGPU_NO_AFFINITY");
+        return e && e[0] == '1';
+    }();
+    if (off) return false;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) return false;
+    for (char *c = bus; *c; ++c) *c = (char)tolower((unsigned char)*c);
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    char line[4096] = {0};
+    const bool got = fgets(line, sizeof line, f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+    CPU_ZERO(out);
+    int n = 0;
+    for (char *p = line; *p;) {  // "0-31,64-95"
+        char *end = nullptr;
+        const long a = strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = strtol(p + 1, &end, 10);
+            p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+            if (c >= 0 && CPU_ISSET((int)c, &allowed)) {
+                CPU_SET((int)c, out);
+                ++n;
+            }
+        while (*p == ',' || *p == ' ' || *p == '\n') ++p;
+    }
+    return n > 0;
+}
+// binds the calling thread for the life of the object, and gives it back what it had
+struct ThreadPlacement {
+    cpu_set_t before;
+    bool bound = false;
+    explicit ThreadPlacement(int device) {
+        cpu_set_t want;
+        if (!device_cpus(device, &want)) return;
+        if (pthread_getaffinity_np(pthread_self(), sizeof before, &before) != 0) return;
+        bound = pthread_setaffinity_np(pthread_self(), sizeof want, &want) == 0;
+    }
+    ~ThreadPlacement() {
+        if (bound) (void)pthread_setaffinity_np(pthread_self(), sizeof before, &before);
+    }
+};
+#else
+struct ThreadPlacement {
+    explicit ThreadPlacement(int) {}
+};
+#endif
+
 // all sub-batches of one device, slot threads side by side
 void run_device(BatchShared &S, int dev_index) {
     zgpu_job::Dev &dv = S.job->devs[dev_index];
@@ -908,11 +1050,14 @@ void run_device(BatchShared &S, int dev_index) {
         if (S.job->subs[i].dev_index == dev_index) mine.push_back(i);
     if (mine.empty()) return;
     std::lock_guard<std::mutex> ctx_lock(dv.ctx->mu);
+    // with several devices at work each one's threads stay on the CPUs next to it
+    const bool place = S.job->devs.size() > 1;
     auto worker = [&](int slot) {
         if (hipSetDevice(dv.device) != hipSuccess) {
             fail_shared(S, ZGPU_E_NODEVICE);
             return;
         }
+        std::unique_ptr<ThreadPlacement> placed(place ? new (std::nothrow) ThreadPlacement(dv.device) : nullptr);
         for (size_t k = (size_t)slot; k < mine.size(); k += kSlots) {
             {
                 std::lock_guard<std::mutex> lk(S.mu);
@@ -1044,13 +1189,59 @@ int zgpu_init(const int *device_ids, int n_devices) {
     int count = 0;
     HIPCHK(hipGetDeviceCount(&count));
     if (count <= 0) return ZGPU_E_NODEVICE;
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_allowed.clear();
+    if (n_devices < 0 || (n_devices > 0 && !device_ids)) return ZGPU_E_ARG;
+    std::vector<int> ids;  // checked as a whole before it replaces the list in force
     for (int i = 0; i < n_devices; ++i) {
         if (device_ids[i] < 0 || device_ids[i] >= count) return ZGPU_E_ARG;
-        g_allowed.push_back(device_ids[i]);
+        ids.push_back(device_ids[i]);
     }
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_allowed.swap(ids);
     return ZGPU_OK;
+}
+
+void *zgpu_host_alloc(uint64_t bytes) {
+    void *p = nullptr;
+    // portable: page-locked for every device, whichever is current now or later
+    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable);
+    if (e != hipSuccess) {
+        g_last_hip = (int)e;
+        return nullptr;
+    }
+    return p;
+}
+
+void zgpu_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+void zgpu_host_trim(void) {
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    std::vector<DeviceState *> devs;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        devs = g_devs;
+    }
+    for (DeviceState *s : devs) {
+        HostCtx *c;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            c = s->host;
+        }
+        if (!c) continue;
+        std::lock_guard<std::mutex> ctx_lock(c->mu);  // no host-buffer call is running on this device
+        DevBuf d;
+        HostBuf h;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            std::swap(d, c->d_res);
+            std::swap(h, c->h_res);
+        }
+        h.release();
+        if (d.p && hipSetDevice(s->device) == hipSuccess) d.release();
+    }
+    if (have_cur) (void)hipSetDevice(cur);
 }
 
 int zgpu_device_count(void) {
@@ -1465,7 +1656,12 @@ static int host_batch_compute(const uint8_t *in, const uint64_t *in_off, uint32_
             }
             if ((rc = get_state(&dv.ds)) != ZGPU_OK) break;
             if ((rc = get_host_ctx(dv.ds, &dv.ctx)) != ZGPU_OK) break;
-            // sub-batches of this device's range: about kSubBytes each, at least one unit
+            // sub-batches of this device's range: about an eighth of the range each -- so that a call of moderate
+            // size already overlaps its copies with its kernels -- between 8 MiB and kSubBytes, at least one unit
+            const uint64_t range_bytes = in_off[cut[d + 1]] - in_off[cut[d]];
+            uint64_t sub_bytes = range_bytes / 8;
+            if (sub_bytes < (8ull << 20)) sub_bytes = 8ull << 20;
+            if (sub_bytes > kSubBytes) sub_bytes = kSubBytes;
             uint32_t u = cut[d];
             while (u < cut[d + 1]) {
                 SubBatch sb;
@@ -1475,7 +1671,7 @@ static int host_batch_compute(const uint8_t *in, const uint64_t *in_off, uint32_
                 do {
                     bytes += in_off[u + 1] - in_off[u];
                     ++u;
-                } while (u < cut[d + 1] && bytes + (in_off[u + 1] - in_off[u]) <= kSubBytes);
+                } while (u < cut[d + 1] && bytes + (in_off[u + 1] - in_off[u]) <= sub_bytes);
                 sb.end = u;
                 sb.res_off = dv.res_need;
                 uint64_t bound = 0;
@@ -1515,9 +1711,11 @@ static int host_batch_compute(const uint8_t *in, const uint64_t *in_off, uint32_
     S.lazy = lazy;
     S.flags = flags;
     S.job = j.get();
+    S.in_locked = is_page_locked(in);
     if (use == 1 && out) {  // one device and the caller's buffer at hand: copy out as sub-batches finish
         S.out = out;
         S.out_cap = out_cap;
+        S.out_locked = is_page_locked(out);
     }
     if (use == 1) {
         run_device(S, 0);
@@ -1703,21 +1901,25 @@ void zgpu_job_release(zgpu_job *j) {
     int cur = 0;
     const bool have_cur = hipGetDevice(&cur) == hipSuccess;
     for (zgpu_job::Dev &dv : j->devs) {
-        if (!dv.d_res.p) continue;
         // the result buffer goes back to its device as the spare one (or is released if the
         // device already has a spare at least as large)
-        bool kept = false;
-        if (dv.ctx) {
-            std::lock_guard<std::mutex> lk(g_mu);
-            if (dv.ctx->d_res.cap < dv.d_res.cap) {
-                std::swap(dv.ctx->d_res, dv.d_res);
-                kept = dv.d_res.p == nullptr;
+        if (dv.d_res.p) {
+            bool kept = false;
+            if (dv.ctx) {
+                std::lock_guard<std::mutex> lk(g_mu);
+                if (dv.ctx->d_res.cap < dv.d_res.cap) {
+                    std::swap(dv.ctx->d_res, dv.d_res);
+                    kept = dv.d_res.p == nullptr;
+                }
             }
+            if (!kept && dv.d_res.p && hipSetDevice(dv.device) == hipSuccess) dv.d_res.release();
         }
-        if (!kept && dv.d_res.p && hipSetDevice(dv.device) == hipSuccess) dv.d_res.release();
+        // the page-locked staging likewise (whether or not the device buffer came about: a failed
+        // allocation there must not leak it), but only up to kSpareHostBytes: page-locked memory
+        // cannot be swapped, and one large archive should not pin gigabytes for the life of the process
         if (dv.h_res.p) {
             bool kept_h = false;
-            if (dv.ctx) {
+            if (dv.ctx && dv.h_res.cap <= kSpareHostBytes) {
                 std::lock_guard<std::mutex> lk(g_mu);
                 if (dv.ctx->h_res.cap < dv.h_res.cap) {
                     std::swap(dv.ctx->h_res, dv.h_res);

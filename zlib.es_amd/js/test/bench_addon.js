@@ -1,7 +1,7 @@
 // Throughput of the N-API path (host buffers, PCIe and JS object creation included).
 //   node zlib.es_amd/js/test/bench_addon.js
 'use strict';
-const { Zlib, deflateChunked } = require('../zlib_gpu.js');
+const { Zlib, deflateChunked, allocInput } = require('../zlib_gpu.js');
 const n = 16384, ub = 65536;
 const big = new Uint8Array(n * ub);
 let x = 12345;
@@ -27,6 +27,14 @@ function time(name, bytes, fn) {
 	return r;
 }
 time('compressBatch, 16384 x 64 KiB views of one buffer', n * ub, () => Zlib.RawDeflate.compressBatch(views, { compressionType: 2 }));
+{
+	// the same input in page-locked memory (allocInput): uploads by DMA instead of through the runtime's staging
+	const locked = allocInput(n * ub);
+	locked.set(big);
+	const lviews = [];
+	for (let i = 0; i < n; ++i) lviews.push(locked.subarray(i * ub, (i + 1) * ub));
+	time('compressBatch, 16384 x 64 KiB views of one allocInput buffer', n * ub, () => Zlib.RawDeflate.compressBatch(lviews, { compressionType: 2 }));
+}
 time('compressBatch, 1024 separate 64 KiB buffers', copies.length * ub, () => Zlib.RawDeflate.compressBatch(copies, { compressionType: 2 }));
 time('deflateChunked, 1 GiB in 1 MiB chunks', n * ub, () => deflateChunked(big, { chunkSize: 1 << 20 }));
 time('RawDeflate#compress, one 64 MiB input', 64 << 20, () => new Zlib.RawDeflate(big.subarray(0, 64 << 20)).compress());

@@ -8,6 +8,7 @@ const assert = require('assert');
 const nodeZlib = require('zlib');
 const { Zlib, deflateChunked, gzipChunked, zlibChunked } = require('../zlib_gpu.js');
 const H = require('./helpers.js');
+const G = require('../zlib_gpu.js');
 
 const size = 76543; // test/browser.es/zlib-test.js:7
 const CT = Zlib.RawDeflate.CompressionType;
@@ -291,6 +292,33 @@ it('RawDeflate.compressBatch', () => {
 
 // results of 4 MiB and more come in a buffer the addon maps itself (huge pages) and hands over as an
 // external ArrayBuffer: the views, a zip archive framed inside such a buffer, and many buffers made and dropped
+it('allocInput: page-locked inputs and the one-step path give the bytes of ordinary ones', () => {
+	// 40 MiB: above the size from which a batch is written straight into a mapping sized for the worst case
+	const n = 40 << 20, ub = 1 << 18;
+	const plain = new Uint8Array(n);
+	let x = 7;
+	for (let i = 0; i < n; ++i) {
+		if ((i & 7) === 0) x = (Math.imul(x, 1664525) + 1013904223) >>> 0;
+		plain[i] = 97 + ((x >>> (4 * (i & 7))) & 15);
+	}
+	const locked = G.allocInput(n);
+	assert.ok(locked instanceof Uint8Array && locked.length === n && locked.byteOffset === 0);
+	locked.set(plain);
+	const cut = (a) => { const v = []; for (let o = 0; o < n; o += ub) v.push(a.subarray(o, o + ub)); return v; };
+	const a = Zlib.RawDeflate.compressBatch(cut(plain), { compressionType: CT.DYNAMIC });
+	const b = Zlib.RawDeflate.compressBatch(cut(locked), { compressionType: CT.DYNAMIC });
+	assert.strictEqual(a.length, b.length);
+	assert.strictEqual(a[0].buffer, a[a.length - 1].buffer);
+	// the ArrayBuffer ends with the last stream: its length is the compressed size, not the mapping's
+	assert.strictEqual(a[0].buffer.byteLength, a[a.length - 1].byteOffset + a[a.length - 1].length);
+	for (let i = 0; i < a.length; ++i) assert.ok(H.equal(a[i], b[i]), 'unit ' + i);
+	for (const i of [0, 1, 77, a.length - 1]) assert.ok(H.equal(nodeZlib.inflateRawSync(Buffer.from(a[i])), plain.subarray(i * ub, (i + 1) * ub)));
+	// below that size the two-step path runs: same bytes
+	const small = Zlib.RawDeflate.compressBatch(cut(plain).slice(0, 8), { compressionType: CT.DYNAMIC });
+	for (let i = 0; i < 8; ++i) assert.ok(H.equal(small[i], a[i]), 'two-step unit ' + i);
+	G.addon.hostTrim();
+});
+
 it('large results: externally mapped output buffers', () => {
 	const rnd = new Uint8Array(6 << 20);
 	let x = 99;

@@ -611,8 +611,15 @@ function nextTickForm(fn) {
 const deflate = nextTickForm(deflateSync);
 const gzip = nextTickForm(gzipSync);
 
+// allocInput(n): a Uint8Array of n bytes in page-locked memory (not part of the reference's surface).  Inputs
+// that live in it -- as a whole or as subarrays -- travel to the GPU by DMA at the full PCIe rate; any other
+// typed array works too, through the runtime's staging.  Freed when the array's buffer is collected.
+function allocInput(n) {
+	return new Uint8Array(addon.allocInput(n));
+}
+
 const Zlib = { RawDeflate, Deflate, Gzip, Zip, CRC32, Adler32 };
 module.exports = {
 	Zlib, RawDeflate, Deflate, Gzip, Zip, CRC32, Adler32, deflateChunked, gzipChunked, zlibChunked,
-	deflate, deflateSync, gzip, gzipSync, addon,
+	deflate, deflateSync, gzip, gzipSync, allocInput, addon,
 };
