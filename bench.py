@@ -239,7 +239,7 @@ def main():
 def brief(r):
     keep = ("value", "unit", "ms_per_step", "config", "ratio_out_over_in", "roofline", "roundtrip_all_units",
             "units_verified_on_gpu", "units_failed", "ratio_vs_ref", "ratio_vs_ref_by_kind", "cpu_baseline", "crc_checked",
-            "bit_exact")
+            "bit_exact", "combine_checked")
     return {k: r[k] for k in keep if k in r}
 
 
@@ -556,29 +556,54 @@ def cpu_leg(args, data, groups, outs, fetched, seconds, kind_of=None):
     }
 
 
+def host_batch_rate(N, in_ptr, off, out_ptr, cap, reps=4):
+    """best rate of zgpu_deflate_batch over `reps` calls on host buffers (GB/s of input), and the output size"""
+    n = off.size - 1
+    out_off = np.zeros(n + 1, dtype=np.uint64)
+    L = N.lib()
+    best = 0.0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        rc = L.zgpu_deflate_batch(in_ptr, off.ctypes.data, n, 2, 0, N.F_FINAL_EACH, out_ptr, cap, out_off.ctypes.data,
+                                  None, None)
+        dt = time.perf_counter() - t0
+        if rc != 0:
+            raise RuntimeError("zgpu_deflate_batch rc %d" % rc)
+        best = max(best, float(off[-1] - off[0]) / dt / 1e9)
+    return best, int(out_off[-1])
+
+
 def end_to_end(ctx):
     """The drop-in path with PCIe in it: the host-buffer entry point through the C ABI on 1 GiB of the
-    default workload, and through the N-API addon under Node when Node is there."""
+    default workload -- the caller's buffers in ordinary memory, then in page-locked memory from
+    zgpu_host_alloc -- and through the N-API addon under Node when Node is there."""
     N, dev = ctx["N"], ctx["dev"]
     nu, ub = 16384, 65536
     data = gen_units(nu, ub, 1, dev).cpu().numpy()
     off = (np.arange(nu + 1, dtype=np.uint64) * np.uint64(ub))
     cap = int(N.deflate_bound(ub) + 48) * nu + 64
     out = np.empty(cap, dtype=np.uint8)
-    out_off = np.zeros(nu + 1, dtype=np.uint64)
-    L = N.lib()
-    best = 0.0
-    for _ in range(4):
-        t0 = time.perf_counter()
-        rc = L.zgpu_deflate_batch(data.ctypes.data, off.ctypes.data, nu, 2, 0, N.F_FINAL_EACH, out.ctypes.data, cap,
-                                  out_off.ctypes.data, None, None)
-        dt = time.perf_counter() - t0
-        if rc != 0:
-            raise RuntimeError("zgpu_deflate_batch rc %d" % rc)
-        best = max(best, nu * ub / dt / 1e9)
+    best, size = host_batch_rate(N, data.ctypes.data, off, out.ctypes.data, cap)
     res = {"c_abi_host_buffers": {"value": round(best, 2), "unit": "GB/s",
                                   "what": "zgpu_deflate_batch on 1 GiB (16384 x 64 KiB units) in pageable host memory, "
                                           "input upload and output download included, best of 4"}}
+    pin_in = pin_out = None
+    try:
+        pin_in, pin_out = N.HostBuffer(data.size), N.HostBuffer(cap)
+        pin_in.array[:] = data
+        best, size2 = host_batch_rate(N, pin_in.ptr, off, pin_out.ptr, cap)
+        same = size2 == size and bytes(pin_out.array[:size]) == bytes(out[:size])
+        res["c_abi_page_locked_buffers"] = {"value": round(best, 2), "unit": "GB/s", "same_bytes": bool(same),
+                                            "what": "the same call with input and output in zgpu_host_alloc memory"}
+        best, _ = host_batch_rate(N, pin_in.ptr, off, out.ctypes.data, cap)
+        res["c_abi_page_locked_input"] = {"value": round(best, 2), "unit": "GB/s",
+                                          "what": "input in zgpu_host_alloc memory, output in pageable memory"}
+    except Exception as e:  # noqa: BLE001
+        res["c_abi_page_locked_buffers"] = {"error": repr(e)}
+    finally:
+        for b in (pin_in, pin_out):
+            if b is not None:
+                b.close()
     node = shutil.which("node")
     script = os.path.join(ROOT, "zlib.es_amd", "js", "test", "bench_addon.js")
     if node and os.path.exists(script):
@@ -588,6 +613,33 @@ def end_to_end(ctx):
         except Exception as e:  # noqa: BLE001
             res["node_addon"] = {"error": repr(e)}
     return res
+
+
+def host_multi_device(ctx, devices):
+    """zgpu_deflate_batch in ONE process over the devices named in zgpu_init: 1 GiB of the default workload
+    per device, in page-locked host memory.  With one device this is end_to_end's c_abi_page_locked_buffers."""
+    N, dev = ctx["N"], ctx["dev"]
+    per, ub = 16384, 65536
+    nu = per * len(devices)
+    off = (np.arange(nu + 1, dtype=np.uint64) * np.uint64(ub))
+    cap = int(N.deflate_bound(ub) + 48) * nu + 64
+    pin_in, pin_out = N.HostBuffer(nu * ub), N.HostBuffer(cap)
+    ids = (ctypes.c_int32 * len(devices))(*devices)
+    try:
+        for d in range(len(devices)):
+            pin_in.array[d * per * ub:(d + 1) * per * ub] = gen_units(per, ub, 1 + d, dev).cpu().numpy()
+        rc = N.lib().zgpu_init(ids, len(devices))
+        if rc != 0:
+            raise RuntimeError("zgpu_init rc %d" % rc)
+        best, size = host_batch_rate(N, pin_in.ptr, off, pin_out.ptr, cap)
+    finally:
+        N.lib().zgpu_init(None, 0)
+        pin_in.close()
+        pin_out.close()
+    return {"value": round(best, 2), "unit": "GB/s", "devices": len(devices), "ratio_out_over_in": round(size / (nu * ub), 5),
+            "what": "one process, zgpu_init over %d device(s), zgpu_deflate_batch on %d GiB in page-locked host memory "
+                    "(units split by bytes over the devices, each device's host threads on its local CPUs), "
+                    "PCIe included, best of 4" % (len(devices), len(devices))}
 
 
 def bench_checksum(ctx, short=False):
@@ -628,6 +680,15 @@ def bench_checksum(ctx, short=False):
                                "cpu_model": cpu_model(),
                                "sample": "first %d bytes, C restatement of src/crc32.js + src/adler32.js" % n}
         res["bit_exact"] = bool((c, a) == (gc, ga))
+        # the whole buffer against the combine of its quarters (the reference has no combine: pinned against
+        # its resumable update in the tests)
+        q = nbytes // 4
+        cc, aa = 0, 1
+        for i in range(4):
+            lo, hi = i * q, (nbytes if i == 3 else (i + 1) * q)
+            pc, pa = z._native.checksum_device(data.data_ptr() + lo, hi - lo, stream)
+            cc, aa = z._native.crc32_combine(cc, pc, hi - lo), z._native.adler32_combine(aa, pa, hi - lo)
+        res["combine_checked"] = bool((cc, aa) == (crc, ad))
     return res
 
 

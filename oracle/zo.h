@@ -80,6 +80,14 @@ int zo_gunzip(const uint8_t *in, size_t n, uint8_t *out, size_t cap,
 /* counts blocks by type while decoding a raw stream: counts[0..2] */
 /* literal and match token counts of the last zo_inflate_raw* call (diagnostics) */
 void zo_inflate_last_tokens(uint32_t out[2]);
+/* dynamic blocks of the next zo_inflate_raw* calls are recorded into blocks[0..cap) (NULL stops it):
+ * code lengths from the header, symbol counts from the decoded tokens */
+typedef struct {
+    uint8_t litlen_len[288], dist_len[32];
+    uint32_t litlen_freq[288], dist_freq[32];
+} zo_block_stats;
+void zo_inflate_record_blocks(zo_block_stats *blocks, int cap);
+int zo_inflate_recorded_blocks(void);
 int zo_inflate_raw_stats(const uint8_t *in, size_t n, uint8_t *out, size_t cap,
                          size_t *out_len, size_t *in_used, uint32_t counts[3]);
 

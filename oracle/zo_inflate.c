@@ -106,11 +106,25 @@ void zo_inflate_last_tokens(uint32_t out[2]) {
     out[1] = g_tok_matches;
 }
 
+/* Per-block record of the dynamic blocks of the last zo_inflate_raw* call, when asked for with
+ * zo_inflate_record_blocks: the code lengths the header carries and how often each symbol was used
+ * (tests weigh a stream's code lengths against the reference's package-merge on the same counts). */
+static zo_block_stats *g_blocks;
+static int g_blocks_cap, g_blocks_n;
+static zo_block_stats *g_cur_block;
+void zo_inflate_record_blocks(zo_block_stats *blocks, int cap) {
+    g_blocks = blocks;
+    g_blocks_cap = cap;
+    g_blocks_n = 0;
+}
+int zo_inflate_recorded_blocks(void) { return g_blocks_n; }
+
 static int inflate_codes(zo_inf *s, const zo_huff *lc, const zo_huff *dc) {
     for (;;) {
         int sym;
         int e = decode_sym(s, lc, &sym);
         if (e) return e;
+        if (g_cur_block) g_cur_block->litlen_freq[sym]++;
         if (sym < 256) {
             if (s->op >= s->cap) return ZO_E_OUTCAP;
             s->out[s->op++] = (uint8_t)sym;
@@ -129,6 +143,7 @@ static int inflate_codes(zo_inf *s, const zo_huff *lc, const zo_huff *dc) {
             e = decode_sym(s, dc, &ds);
             if (e) return e;
             if (ds >= 30) return ZO_E_SYMBOL;
+            if (g_cur_block) g_cur_block->dist_freq[ds]++;
             e = get_bits(s, DEXT[ds], &x);
             if (e) return e;
             size_t dist = DBASE[ds] + x;
@@ -207,7 +222,16 @@ static int inflate_dynamic(zo_inf *s) {
     if (err < 0 || (err > 0 && nlen - lc.count[0] != 1)) return ZO_E_CODELENS;
     err = build_huff(&dc, lengths + nlen, ndist);
     if (err < 0 || (err > 0 && ndist - dc.count[0] != 1)) return ZO_E_CODELENS;
-    return inflate_codes(s, &lc, &dc);
+    g_cur_block = NULL;
+    if (g_blocks && g_blocks_n < g_blocks_cap) {
+        g_cur_block = &g_blocks[g_blocks_n++];
+        memset(g_cur_block, 0, sizeof *g_cur_block);
+        memcpy(g_cur_block->litlen_len, lengths, (size_t)nlen);
+        memcpy(g_cur_block->dist_len, lengths + nlen, (size_t)ndist);
+    }
+    e = inflate_codes(s, &lc, &dc);
+    g_cur_block = NULL;
+    return e;
 }
 
 static int inflate_stored(zo_inf *s) {

@@ -188,6 +188,28 @@ def inflate_raw(data, cap, want_used=False, want_stats=False):
     return (res, used.value) if want_used else res
 
 
+BLOCK_DTYPE = np.dtype([("litlen_len", np.uint8, 288), ("dist_len", np.uint8, 32),
+                        ("litlen_freq", np.uint32, 288), ("dist_freq", np.uint32, 32)])
+
+
+def block_stats(data, cap, max_blocks=64):
+    """The dynamic blocks of a raw stream: per block the code lengths its header carries and the
+    number of times each literal/length and distance symbol is used (a structured array)."""
+    a = _arr(data)
+    blocks = np.zeros(max_blocks, dtype=BLOCK_DTYPE)
+    assert blocks.itemsize == 288 + 32 + 4 * 288 + 4 * 32
+    L = lib()
+    L.zo_inflate_record_blocks.argtypes = [C.c_void_p, C.c_int]
+    L.zo_inflate_record_blocks.restype = None
+    L.zo_inflate_record_blocks(blocks.ctypes.data, max_blocks)
+    try:
+        inflate_raw(a, cap)
+        n = L.zo_inflate_recorded_blocks()
+    finally:
+        L.zo_inflate_record_blocks(None, 0)
+    return blocks[:n]
+
+
 def inflate_zlib(data, cap):
     a = _arr(data)
     out = np.zeros(max(cap, 1), dtype=np.uint8)
