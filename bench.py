@@ -409,7 +409,7 @@ def measured_traffic(workload, cfg, args):
 
 def measured_lds(workload, cfg, args):
     """LDS-pipe and VALU occupancy of the search kernel from the same committed counter passes
-    (measured on 8192 units of this mix), or None for another workload."""
+    (measured on the same 65536-unit batch), or None for another workload."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except (OSError, ValueError):
@@ -420,7 +420,7 @@ def measured_lds(workload, cfg, args):
         return None
     lds = dict(t.get("lds") or {})
     if lds:
-        lds["source"] = ("replayed from profiles/traffic.json (rocprofv3 --pmc SQ_* passes on 8192 units of this mix, %s); "
+        lds["source"] = ("replayed from profiles/traffic.json (rocprofv3 --pmc SQ_* passes on this 65536-unit batch, %s); "
                          "not measured in this run" % t.get("source"))
     return lds
 

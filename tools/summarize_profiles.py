@@ -41,7 +41,7 @@ def main():
     os.makedirs(DST, exist_ok=True)
     # kernel stats
     for sub, name in (("stats", "bench_kernel_stats"), ("ckstats", "checksum_kernel_stats"), ("zipstats", "zip_kernel_stats"),
-                      ("gzipstats", "gzip_kernel_stats")):
+                      ("gzipstats", "gzip_kernel_stats"), ("fixedstats", "fixed_kernel_stats")):
         p = find(sub, "kernel_stats.csv")
         if p:
             rows = list(csv.reader(open(p)))
@@ -49,7 +49,7 @@ def main():
                 csv.writer(f).writerows(rows)
     # counters, per launch
     out = {}
-    for sub in ("fetch", "write", "sq1", "sq2", "sq2_chain1", "sq2_fan0", "ckfetch"):
+    for sub in ("fetch", "write", "sq1", "sq2", "sq2_chain1", "sq2_deep0", "ckfetch"):
         agg, calls = counters(sub)
         for k, v in agg.items():
             if not k.startswith("zgpu_"):
@@ -74,13 +74,13 @@ def main():
                     "128-B read requests at 64 B); the token stream between the two kernels is part of it",
             "source": "%s_pmc.json" % tag,
         }
-        # LDS side of the search kernel (sq1 / sq2 passes, 8192 units of the same mix): share of the
+        # LDS side of the search kernel (sq1 / sq2 passes, the same 65536-unit batch): share of the
         # kernel's cycles in which a CU's LDS pipe was busy, and in which it replayed bank conflicts.
         # SQ_BUSY_CYCLES is summed over the 32 shader engines; 256 CUs.
         try:
             q1, q2 = out["sq1"]["zgpu_deflate_kernel"], out["sq2"]["zgpu_deflate_kernel"]
             cu_cycles = q1["SQ_BUSY_CYCLES"] / 32.0 * 256.0
-            nbytes = 8192 * 65536
+            nbytes = 65536 * 65536
             traffic["lds"] = {
                 "kernel": "zgpu_deflate_kernel",
                 "lds_pipe_busy_frac": round(q2["SQ_LDS_IDX_ACTIVE"] / cu_cycles, 4),
@@ -99,9 +99,9 @@ def main():
                         "SIMD-cycles and the share of the SIMD's peak issue rate is 2 x SQ_INSTS_VALU / SQ_WAVE_CYCLES; "
                         "the wave_cycles_* shares split the waves' own time (SQ_ACTIVE_INST_ANY, SQ_WAIT_ANY, SQ_WAIT_INST_ANY)",
             }
-            # LDS bank-conflict cycles with parts of the search switched off: what the chain walk and the fan add
+            # LDS bank-conflict cycles with parts of the search switched off: what the chain walk and the deep walk add
             conf = {"default": q2["SQ_LDS_BANK_CONFLICT"]}
-            for sub, name in (("sq2_chain1", "max_chain_1"), ("sq2_fan0", "probe_fans_0")):
+            for sub, name in (("sq2_chain1", "max_chain_1"), ("sq2_deep0", "deep_chain_0")):
                 if sub in out and "zgpu_deflate_kernel" in out[sub]:
                     conf[name] = out[sub]["zgpu_deflate_kernel"]["SQ_LDS_BANK_CONFLICT"]
             traffic["lds"]["bank_conflict_cycles_by_setting"] = conf

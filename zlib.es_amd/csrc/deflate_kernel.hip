@@ -1174,12 +1174,10 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     // (incrementing-run units: sizes +0.1 %).  Only with the deep walk on: without it those positions
                     // are where the parse lands after a match that was cut short.
                     int walk_budget = P.max_chain;
-#ifndef ZGPU_NO_RUNLIKE
                     if (!THOROUGH && !whole && P.deep > 0 && P.max_chain > 3) {
                         const uint32_t cb = from_below(c, 0xfffffffeu);
                         if (__builtin_popcountll(__ballot(p + 4 <= n && ((c - cb) & 0xffffu) == 1u)) >= 48) walk_budget = 3;
                     }
-#endif
                     if (!whole) {
                         // pass 1, lane per position: walk the hash chain.  A candidate costs one
                         // LDS round trip: its chain link and its first 16 bytes (aligned dword
