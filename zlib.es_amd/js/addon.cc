@@ -395,8 +395,11 @@ napi_value DeflateBatch(napi_env env, napi_callback_info info) {
                 std::thread toucher[2];
                 for (int t = 0; t < 2; ++t)
                     toucher[t] = std::thread([=] {
-                        volatile uint8_t *p = (volatile uint8_t *)start;
-                        for (uint64_t o = (pre / 2 * t) & ~(uint64_t)4095, e = t ? pre : pre / 2; o < e; o += 4096) p[o] = 0;
+                        // an atomic OR of nothing: a write access, so the page comes into being, that cannot
+                        // undo a byte the library has stored there in the meantime
+                        uint8_t *p = (uint8_t *)start;
+                        for (uint64_t o = (pre / 2 * t) & ~(uint64_t)4095, e = t ? pre : pre / 2; o < e; o += 4096)
+                            (void)__atomic_fetch_or(p + o, (uint8_t)0, __ATOMIC_RELAXED);
                     });
                 rc = g.deflate_batch(src, in_off.data(), n, ctype, lazy, flags, (uint8_t *)start, bound, out_off.data(),
                                      want_crc ? crc.data() : nullptr, want_adler ? adler.data() : nullptr);
