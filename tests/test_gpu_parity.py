@@ -108,7 +108,6 @@ DEFAULT_EXCEPTIONS = {
     # 2-3 letter alphabets: every 4-byte key has thousands of earlier occurrences and the best of
     # them is a few bytes longer than the best of the first eight: 1.20-1.28 x / 1.04-1.056 x
     ("small-alpha", 1): 1.29, ("small-alpha", 2): 1.07,
-    ("runs", 1): 1.06,  # 4-value runs under FIXED: 1.045 x (1.19 before the probe-ahead step); DYNAMIC 1.002 x
 }
 
 
@@ -130,7 +129,7 @@ def test_ratio_vs_reference_case_by_case(z, golden, ctype):
 
 # the content kinds of bench.py's batch (unit index mod 20), and what each may take of the reference's size
 BENCH_KINDS = {"text": (0, 10), "incrementing runs": (10, 15), "random": (15, 18), "low entropy": (18, 20)}
-BENCH_KIND_BOUNDS = {("low entropy", 1): 1.06}  # 4-value runs under FIXED, as ("runs", 1) above
+BENCH_KIND_BOUNDS = {}  # none: every kind meets the bar in both modes
 
 
 @pytest.mark.parametrize("ctype", [1, 2])
@@ -162,7 +161,6 @@ def test_ratio_with_long_match_steps(z, golden, ctype):
     finally:
         z._native.set_long_match()
     exceptions = dict(DEFAULT_EXCEPTIONS)
-    exceptions["runs", 1] = 1.05
     bad = [(c["spec"], s, c["raw"][str(ctype)]["len"]) for c, s in zip(cases, sizes)
            if s > _case_bound(c, ctype, exceptions) * c["raw"][str(ctype)]["len"]]
     assert not bad, bad
