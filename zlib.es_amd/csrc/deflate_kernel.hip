@@ -58,6 +58,9 @@ constexpr uint32_t WMASK = 0x7fff;  // chain slots (32 Ki positions)
 #ifndef ZGPU_LAG_FULL
 #define ZGPU_LAG_FULL 54
 #endif
+#ifndef ZGPU_PEND_FULL
+#define ZGPU_PEND_FULL 3
+#endif
 constexpr uint32_t LAG = ZGPU_LAG_FULL;  // an item starts only when all items more than LAG back are parsed
 constexpr uint32_t TAIL_MAXDIST = 16;  // tail walks start from matches at most this far back (runs, short periods)
 constexpr int TAIL_STEPS = 8;         // candidates of a tail walk
@@ -89,7 +92,7 @@ struct CfgFull {  // 32 KiB window, one workgroup per CU
     static constexpr int WG = 1024;
     static constexpr int WG_PER_CU = 1;
     static constexpr uint32_t RING = 65536, CHAIN = 32768, HBITS = 13, NSLOT = 64, NSLOT_E = 128, LAG = ZGPU_LAG_FULL;
-    static constexpr int PEND = 3;
+    static constexpr int PEND = ZGPU_PEND_FULL;
 };
 #ifndef ZGPU_HALF_HBITS
 #define ZGPU_HALF_HBITS 11
