@@ -142,6 +142,26 @@ int zgpu_set_search(int max_chain, int nice_length);
  * 1.01-1.02 x at 96, the default, and at 128; such input runs at about 80 % of
  * its deep_chain 0 speed with the default. */
 int zgpu_set_long_match(int deep_chain, int probe_fans);
+/* Dense input.  In a unit made of a handful of byte values in no particular
+ * order (2-6 values: bilevel noise, nucleotide letters) every 4-byte key has
+ * hundreds to thousands of earlier occurrences and the longest of them is a few
+ * bytes longer than the longest of the nearest max_chain -- at every position,
+ * which no bounded walk makes up for (1.03-1.34 x the reference's size under
+ * FIXED, up to 1.11 x under DYNAMIC at the default max_chain).  Every unit of at
+ * least 4 KiB is therefore classified on the device before it is searched
+ * (sixteen 64-byte samples: at most six distinct byte values, fewer than three
+ * in four bytes equal to their successor), and the units of that class are
+ * searched the reference's way (src/rawdeflate.js:370-395: every candidate
+ * compared to its full length, the longest wins, the nearest among equals; the
+ * parse defers a match only below the caller's own `lazy`), along at most
+ * max_chain candidates per position (0..32768, default 1024; 0 = no such
+ * pass).  Such units then come out at 0.99-1.02 x the reference's size in both
+ * modes (0.99-1.02 x; the chain budget matters for two and three values only:
+ * 128 leaves two values at 1.09 x under FIXED) and run at 1-13 GB/s per GPU
+ * (two values: 1, three: 2.6, four: 6, six: 13) instead of 35; other input pays
+ * the classification and an empty launch, under 0.1 % of its time.  Not applied
+ * where zgpu_set_search already asks for as much. */
+int zgpu_set_dense_search(int max_chain);
 /* In a batch of fewer than 16 units per compute unit, a unit longer than two
  * pieces is cut into pieces (batch bytes / 16 / compute units, at least
  * 128 KiB, at most piece_bytes) which are compressed side by side as chunks of

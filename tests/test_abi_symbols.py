@@ -71,4 +71,5 @@ def test_argument_errors_need_no_gpu():
     assert L.zgpu_set_search(0, 32) == -2 and L.zgpu_set_search(8, 259) == -2 and L.zgpu_set_search(N.DEFAULT_MAX_CHAIN, N.DEFAULT_NICE_LENGTH) == 0
     assert L.zgpu_set_split(4096) == -2 and L.zgpu_set_split(1 << 20) == 0
     assert L.zgpu_set_min_lazy(-1) == -2 and L.zgpu_set_min_lazy(258) == 0
+    assert L.zgpu_set_dense_search(-1) == -2 and L.zgpu_set_dense_search(N.DEFAULT_DENSE_CHAIN) == 0
     assert b"compression type" in ctypes.cast(L.zgpu_strerror(-2), ctypes.c_char_p).value

@@ -98,17 +98,13 @@ def test_roundtrip_golden_cases(z, golden, ctype):
                 assert s == c["raw"]["0"]["len"]  # stored framing is byte-identical in size
 
 
-# Size against the reference, case by case, at the shipped search settings.  Cases not listed
-# here meet the 3 % bar on their own; the listed ones are the known exceptions of the bounded
-# search, held to what was measured (+1 %) so that they cannot get worse unnoticed:
-# (generator, compressionType) -> bound.  Runs of incrementing bytes (the reference's own
-# makeRandomSequentialData) are not among them: the deep walk of the default settings finds
-# the longest of their ~100 equally near candidates (1.005-1.021 x).
-DEFAULT_EXCEPTIONS = {
-    # 2-3 letter alphabets: every 4-byte key has thousands of earlier occurrences and the best of
-    # them is a few bytes longer than the best of the first eight: 1.20-1.28 x / 1.04-1.056 x
-    ("small-alpha", 1): 1.29, ("small-alpha", 2): 1.07,
-}
+# Size against the reference, case by case, at the shipped search settings: every named case
+# meets the 3 % bar on its own.  Runs of incrementing bytes (the reference's own
+# makeRandomSequentialData) do since the deep walk finds the longest of their ~100 equally near
+# candidates (1.005-1.021 x); 2-3-letter alphabets since units of that kind are found on the
+# device and searched the reference's way (tests/test_gpu_dense_class.py).  The table is for
+# settings that switch such steps off: (generator, compressionType) -> bound.
+DEFAULT_EXCEPTIONS = {}
 
 
 def _case_bound(case, ctype, exceptions):

@@ -28,7 +28,7 @@ def test_addon_loads_and_exports():
         pytest.fail("zgpu_addon.node missing: run __graft_entry__.build() / make -C zlib.es_amd/js")
     r = _node("const a=require('./zgpu_addon.node'); console.log(Object.keys(a).sort().join(','))")
     assert r.returncode == 0, r.stderr
-    assert r.stdout.strip() == "adler32Combine,allocInput,checksum,crc32Combine,deflateBatch,deflateBound,hostDevices,hostTrim,init,setLongMatch,setMinLazy,setSearch,setSplit"
+    assert r.stdout.strip() == "adler32Combine,allocInput,checksum,crc32Combine,deflateBatch,deflateBound,hostDevices,hostTrim,init,setDenseSearch,setLongMatch,setMinLazy,setSearch,setSplit"
 
 
 @needs_node

@@ -18,7 +18,7 @@ F_FINAL_EACH, F_SYNC_ALIGN, F_FINAL_LAST, F_PRIME_WINDOW, F_WANT_CRC, F_WANT_ADL
 # every symbol include/zgpu.h declares
 SYMBOLS = [
     "zgpu_init", "zgpu_device_count", "zgpu_shutdown", "zgpu_host_devices", "zgpu_partition_units", "zgpu_strerror", "zgpu_last_hip_error", "zgpu_set_search", "zgpu_set_split",
-    "zgpu_set_min_lazy", "zgpu_set_long_match",
+    "zgpu_set_min_lazy", "zgpu_set_long_match", "zgpu_set_dense_search",
     "zgpu_deflate_bound", "zgpu_deflate_batch", "zgpu_deflate_batch_begin", "zgpu_deflate_batch_finish",
     "zgpu_deflate_batch_finish_spaced",
     "zgpu_job_release", "zgpu_plan_create", "zgpu_plan_destroy",
@@ -68,6 +68,8 @@ def lib():
     L.zgpu_set_split.argtypes = [C.c_uint64]
     L.zgpu_set_min_lazy.restype = i32
     L.zgpu_set_min_lazy.argtypes = [i32]
+    L.zgpu_set_dense_search.restype = i32
+    L.zgpu_set_dense_search.argtypes = [i32]
     L.zgpu_set_long_match.restype = i32
     L.zgpu_set_long_match.argtypes = [i32, i32]
     L.zgpu_deflate_bound.restype = u64
@@ -193,6 +195,15 @@ def host_trim():
 
 def set_split(piece_bytes):
     _check(lib().zgpu_set_split(piece_bytes), "zgpu_set_split")
+
+
+DEFAULT_DENSE_CHAIN = 1024
+
+
+def set_dense_search(max_chain=DEFAULT_DENSE_CHAIN):
+    """Chain budget of the second, reference-like search that units of a handful of byte values get
+    (0 = no such pass); without arguments back to the default."""
+    _check(lib().zgpu_set_dense_search(max_chain), "zgpu_set_dense_search")
 
 
 def set_min_lazy(min_lazy):

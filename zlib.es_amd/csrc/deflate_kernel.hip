@@ -2352,6 +2352,47 @@ zgpu_emit_slots_kernel(EParams P) {
     emit_units<256, false>(P, lds);
 }
 
+// ---- content class of a unit: "dense" = a handful of byte values in no particular order ----
+// In such data every 4-byte key has hundreds to thousands of earlier occurrences and the longest of them
+// is a few bytes longer than the longest of the nearest eight, at *every* position: the bounded walk of
+// the search kernel leaves 3-30 % of size against the reference's exhaustive one (src/rawdeflate.js:370-395),
+// where on other data it leaves nothing.  Units of that class are searched again by the thorough kernel
+// variant over the list written here (the second search replaces the tokens of the first).
+// One wave per unit: ZGPU_CLS_CHUNKS chunks of 64 bytes spread evenly over the unit; dense = at most
+// ZGPU_CLS_VALUES distinct byte values among them, and fewer than three in four bytes equal to their successor
+// (runs have few values too, but their long matches are the first candidates of their chains).
+#define ZGPU_CLS_CHUNKS 16
+#define ZGPU_CLS_VALUES 6
+#define ZGPU_CLS_MIN_BYTES 4096u
+extern "C" __global__ void __launch_bounds__(256)
+zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_first, uint32_t unit_end,
+                     uint32_t *dense_list, uint32_t *dense_count) {
+    __shared__ uint8_t seen[4][256];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t u = unit_first + blockIdx.x * 4u + w;
+    for (int i = 0; i < 4; ++i) seen[w][lane * 4 + i] = 0;
+    __syncthreads();
+    const uint64_t uo = u < unit_end ? in_off[u] : 0;
+    const uint64_t un = u < unit_end ? in_off[u + 1] - uo : 0;
+    const bool live = un >= ZGPU_CLS_MIN_BYTES;  // uniform per wave; a unit has less than 4 GiB (ZGPU_MAX_UNIT_BYTES)
+    uint32_t equal = 0;
+    if (live) {
+        const uint32_t n = (uint32_t)un, stride = (n - 65u) / (ZGPU_CLS_CHUNKS - 1);
+        const uint8_t *src = in + uo;
+        for (uint32_t c = 0; c < ZGPU_CLS_CHUNKS; ++c) {
+            const uint32_t at = c * stride + lane;  // at + 1 <= 15 * stride + 64 <= n - 1
+            const uint8_t b0 = src[at], b1 = src[at + 1];
+            seen[w][b0] = 1;
+            equal += (uint32_t)__builtin_popcountll(__ballot(b0 == b1));
+        }
+    }
+    __syncthreads();
+    uint32_t values = 0;
+    for (int i = 0; i < 4; ++i) values += (uint32_t)__builtin_popcountll(__ballot(seen[w][i * 64 + lane] != 0));
+    if (live && lane == 0 && values <= ZGPU_CLS_VALUES && equal * 4u < 3u * 64u * ZGPU_CLS_CHUNKS)
+        dense_list[atomicAdd(dense_count, 1u)] = u;
+}
+
 // ---- stored blocks (CompressionType.NONE; makeNocompressBlock rawdeflate.js:131-153)
 // The sizes follow from the unit sizes alone, so the host has the final offsets (slot_off) ready.
 extern "C" __global__ void __launch_bounds__(256)

@@ -34,6 +34,9 @@ std::atomic<int> g_max_chain{8};
 std::atomic<int> g_nice{32};
 std::atomic<uint64_t> g_split_bytes{1ull << 20};  // units longer than twice this are cut into pieces of at most this size
 std::atomic<int> g_deep{96};       // long-match steps of the search kernel: deep-walk budget (0 = off)
+// units of the "dense" content class (zgpu_classify_kernel) are searched again with this chain budget,
+// nice_length 258 and the caller's own lazy value; 0 = no such pass
+std::atomic<int> g_dense_chain{1024};
 std::atomic<int> g_min_lazy{258};  // the parse always looks one position ahead unless told otherwise
 std::atomic<int> g_live{0};        // plans and jobs alive: zgpu_shutdown leaves the device state alone while any is
 unsigned long long *g_prof = nullptr;  // diagnostic builds only
@@ -294,9 +297,10 @@ void free_ck_scratch(CkScratch *c) {
 struct Knobs {
     int max_chain, nice, deep, min_lazy;
     uint64_t split;
+    int dense_chain;
 };
 Knobs read_knobs() {
-    return Knobs{g_max_chain.load(), g_nice.load(), g_deep.load(), g_min_lazy.load(), g_split_bytes.load()};
+    return Knobs{g_max_chain.load(), g_nice.load(), g_deep.load(), g_min_lazy.load(), g_split_bytes.load(), g_dense_chain.load()};
 }
 
 }  // namespace
@@ -338,6 +342,10 @@ struct zgpu_plan {
     // listed at d_list + cls_at[c]; all zero: the round is of one class (by max_bytes) and runs as a range
     struct Round { uint32_t first, end; uint64_t max_bytes; uint32_t cls_at[3] = {0, 0, 0}, cls_len[3] = {0, 0, 0}; };
     uint32_t *d_list = nullptr;
+    // units of the dense content class, found on the device when the plan runs: b_dense holds the largest
+    // round's worth of unit numbers (the tail 0xffffffff = no unit); the count is word 6 * rounds + 1 of b_counter
+    DevBuf b_dense;
+    uint32_t dense_cap = 0;  // 0: the plan has no such pass
     std::vector<Round> rounds;  // units whose tokens share the token buffer at one time
     std::vector<uint32_t> h_status;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -345,7 +353,7 @@ struct zgpu_plan {
     bool pooled = false;  // owned by a device's host context (not counted as a caller's live plan)
     void release_buffers() {
         for (DevBuf *b : {&d_tab, &b_out_off, &b_unit_out_off, &b_out_size, &b_status, &b_crc, &b_adler, &b_counter, &b_tok,
-                          &b_hist, &b_ntok, &b_state, &b_out_tmp, &b_seg_crc, &b_seg_adler})
+                          &b_hist, &b_ntok, &b_state, &b_out_tmp, &b_seg_crc, &b_seg_adler, &b_dense})
             b->release();
     }
 };
@@ -665,6 +673,13 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
         ENS(p->b_tok, (size_t)tok_buf_tokens * 2 + 64);
         ENS(p->b_hist, (size_t)n_blocks * 320 * 4);
         ENS(p->b_ntok, (size_t)n_blocks * 4);
+    }
+    // the dense-class pass: not where the whole plan is searched thoroughly or at least as deep anyway
+    p->dense_cap = 0;
+    if (ctype != ZGPU_NONE && p->knobs.dense_chain > p->knobs.max_chain && p->knobs.nice <= 32) {
+        for (const auto &r : p->rounds)
+            if (r.end - r.first > p->dense_cap) p->dense_cap = r.end - r.first;
+        ENS(p->b_dense, (size_t)p->dense_cap * 4);
     }
     if (p->split) ENS(p->b_unit_out_off, (size_t)(n_units + 1) * 8);
     if (p->n_segs) {
@@ -1313,6 +1328,12 @@ int zgpu_set_split(uint64_t piece_bytes) {
     return ZGPU_OK;
 }
 
+int zgpu_set_dense_search(int max_chain) {
+    if (max_chain < 0 || max_chain > 32768) return ZGPU_E_ARG;
+    g_dense_chain = max_chain;
+    return ZGPU_OK;
+}
+
 int zgpu_set_min_lazy(int min_lazy) {
     if (min_lazy < 0 || min_lazy > 258) return ZGPU_E_ARG;
     g_min_lazy = min_lazy;
@@ -1396,6 +1417,14 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             P.prof = g_prof;
             // one launch over the round's range, or one per size class over its list
             const auto &R = p->rounds[r];
+            if (p->dense_cap) {
+                // which units are of the dense class (their list starts over with every round)
+                HIPCHK(hipMemsetAsync(p->b_dense.p, 0xff, (size_t)cnt * 4, st));
+                if (r) HIPCHK(hipMemsetAsync(p->d_counter() + 6 * p->rounds.size(), 0, 8, st));
+                hipLaunchKernelGGL(zgpu_classify_kernel, dim3((cnt + 3) / 4), dim3(256), 0, st, (const uint8_t *)d_in,
+                                   p->d_in_off, first, end, p->b_dense.as<uint32_t>(),
+                                   p->d_counter() + 6 * p->rounds.size() + 1);
+            }
             const bool has_lists = R.cls_len[0] + R.cls_len[1] + R.cls_len[2] != 0;
             const bool listed = has_lists && p->search_by_class;
             for (int c = 0; c < 3; ++c) {
@@ -1430,6 +1459,22 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
                     hipLaunchKernelGGL(zgpu_deflate_half_kernel, dim3(n_here < 2 * cus ? n_here : 2 * cus), dim3(1024), 0, st, P);
                 } else
                     hipLaunchKernelGGL(zgpu_deflate_kernel, dim3(n_here < cus ? n_here : cus), dim3(1024), 0, st, P);
+            }
+            if (p->dense_cap) {
+                // ... and those are searched again as the reference searches (chain budget dense_chain, a match
+                // is good enough only at 258, lazy as the caller gave it); the tokens, counts and histograms of
+                // the first search are overwritten.  The list ends at its first 0xffffffff entry: a workgroup
+                // that draws it is done, so with no dense unit in the round this launch is a few microseconds.
+                P.unit_list = p->b_dense.as<uint32_t>();
+                P.list_len = cnt;
+                P.unit_first = 0;
+                P.unit_end = 0xffffffffu;
+                P.counter = p->d_counter() + 6 * p->rounds.size();
+                P.max_chain = p->knobs.dense_chain;
+                P.nice = 258;
+                P.lazy = p->lazy;
+                const uint32_t cus = (uint32_t)p->ds->cus;
+                hipLaunchKernelGGL(zgpu_deflate_thorough_kernel, dim3(cnt < cus ? cnt : cus), dim3(1024), 0, st, P);
             }
             if (r == 0) HIPCHK(hipEventRecord(p->ev[4], st));
             EParams E;

@@ -47,6 +47,7 @@ struct Lib {
     fn_strerror strerror_ = nullptr;
     fn_set2 set_search = nullptr;
     fn_set1 set_min_lazy = nullptr;
+    fn_set1 set_dense_search = nullptr;
     fn_set2 set_long_match = nullptr;
     int (*init)(const int *, int) = nullptr;
     int (*device_count)() = nullptr;
@@ -229,6 +230,7 @@ napi_value Init_(napi_env env, napi_callback_info info) {
     g.strerror_ = (fn_strerror)dlsym(h, "zgpu_strerror");
     g.set_search = (fn_set2)dlsym(h, "zgpu_set_search");
     g.set_min_lazy = (fn_set1)dlsym(h, "zgpu_set_min_lazy");
+    g.set_dense_search = (fn_set1)dlsym(h, "zgpu_set_dense_search");
     g.set_long_match = (fn_set2)dlsym(h, "zgpu_set_long_match");
     g.set_split = (int (*)(uint64_t))dlsym(h, "zgpu_set_split");
     g.init = (int (*)(const int *, int))dlsym(h, "zgpu_init");
@@ -238,7 +240,7 @@ napi_value Init_(napi_env env, napi_callback_info info) {
     g.host_free = (void (*)(void *))dlsym(h, "zgpu_host_free");
     g.host_trim = (void (*)())dlsym(h, "zgpu_host_trim");
     if (!g.deflate_batch || !g.batch_begin || !g.batch_finish || !g.batch_finish_spaced || !g.job_release || !g.checksum || !g.bound || !g.crc_combine || !g.adler_combine || !g.strerror_ ||
-        !g.set_search || !g.set_min_lazy || !g.set_split || !g.set_long_match || !g.init || !g.device_count || !g.host_devices ||
+        !g.set_search || !g.set_min_lazy || !g.set_dense_search || !g.set_split || !g.set_long_match || !g.init || !g.device_count || !g.host_devices ||
         !g.host_alloc || !g.host_free || !g.host_trim) {
         dlclose(h);
         napi_throw_error(env, nullptr, "libzgpu.so lacks an expected symbol");
@@ -595,6 +597,18 @@ napi_value SetMinLazy(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 
+napi_value SetDenseSearch(napi_env env, napi_callback_info info) {
+    if (!need_lib(env)) return nullptr;
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    int32_t a = 0;
+    NAPI_OK(napi_get_value_int32(env, argv[0], &a));
+    int rc = g.set_dense_search(a);
+    if (rc) return throw_zgpu(env, "zgpu_set_dense_search", rc);
+    return nullptr;
+}
+
 napi_value SetSplit(napi_env env, napi_callback_info info) {
     if (!need_lib(env)) return nullptr;
     size_t argc = 1;
@@ -657,6 +671,7 @@ napi_value ModuleInit(napi_env env, napi_value exports) {
         {"setSearch", nullptr, SetSearch, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setLongMatch", nullptr, SetLongMatch, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setMinLazy", nullptr, SetMinLazy, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setDenseSearch", nullptr, SetDenseSearch, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setSplit", nullptr, SetSplit, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"allocInput", nullptr, AllocInput, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"hostTrim", nullptr, HostTrim, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
