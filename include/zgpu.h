@@ -142,25 +142,32 @@ int zgpu_set_search(int max_chain, int nice_length);
  * 1.01-1.02 x at 96, the default, and at 128; such input runs at about 80 % of
  * its deep_chain 0 speed with the default. */
 int zgpu_set_long_match(int deep_chain, int probe_fans);
-/* Dense input.  In a unit made of a handful of byte values in no particular
- * order (2-6 values: bilevel noise, nucleotide letters) every 4-byte key has
- * hundreds to thousands of earlier occurrences and the longest of them is a few
- * bytes longer than the longest of the nearest max_chain -- at every position,
- * which no bounded walk makes up for (1.03-1.34 x the reference's size under
- * FIXED, up to 1.11 x under DYNAMIC at the default max_chain).  Every unit of at
- * least 4 KiB is therefore classified on the device before it is searched
- * (sixteen 64-byte samples: at most six distinct byte values, fewer than three
- * in four bytes equal to their successor), and the units of that class are
- * searched the reference's way (src/rawdeflate.js:370-395: every candidate
- * compared to its full length, the longest wins, the nearest among equals; the
- * parse defers a match only below the caller's own `lazy`), along at most
- * max_chain candidates per position (0..32768, default 1024; 0 = no such
- * pass).  Such units then come out at 0.99-1.02 x the reference's size in both
- * modes (0.99-1.02 x; the chain budget matters for two and three values only:
- * 128 leaves two values at 1.09 x under FIXED) and run at 1-13 GB/s per GPU
- * (two values: 1, three: 2.6, four: 6, six: 13) instead of 35; other input pays
- * the classification and an empty launch, under 0.1 % of its time.  Not applied
- * where zgpu_set_search already asks for as much. */
+/* Dense input.  Where a few byte values carry a unit, or the unit is made of
+ * short runs (two to six equally likely values, skewed alphabets, Markov
+ * sources, words over ACGT or 01, 16-bit samples of small range, runs of up to
+ * a hundred bytes) every 4-byte key has hundreds to thousands of earlier
+ * occurrences and the longest of them is a few bytes longer than the longest
+ * of the nearest max_chain -- at every position, which no bounded walk makes
+ * up for (1.03-1.47 x the reference's size under FIXED, up to 1.29 x under
+ * DYNAMIC at the default max_chain).  Every unit of at least 4 KiB is
+ * therefore classified on the device before it is searched, from 32 samples of
+ * 64 bytes: two sampled bytes are equal with a chance of at least 0.155 (what
+ * six equally likely values give; text: 0.05-0.08) or at least half of the
+ * sampled bytes equal their successor, and fewer than 45 % of the samples are
+ * one value throughout (runs of hundreds of bytes need nothing more than the
+ * default search).  The units of that class are searched the reference's way
+ * (src/rawdeflate.js:370-395: every candidate compared to its full length, the
+ * longest wins, the nearest among equals; the parse defers a match only below
+ * the caller's own `lazy`), along at most max_chain candidates per position
+ * (0..32768, default 2048; 0 = no such pass).  Such units then come out at
+ * 0.99-1.02 x the reference's size in both modes (1024: up to 1.03 x, 4096: up
+ * to 1.01 x, at half and twice the time) and take 3-130 ms per 64 KiB on their
+ * compute unit instead of 0.4 -- 0.1-5 GB/s per GPU, where one CPU core runs
+ * the reference's algorithm at 0.3-1.6 MB/s; other input pays the
+ * classification and an empty launch, 0.2 % of its time.  The second search
+ * starts when the first has finished: a batch with a few such units among
+ * others ends later by the time of its slowest dense unit.  Not applied where
+ * zgpu_set_search already asks for as much. */
 int zgpu_set_dense_search(int max_chain);
 /* In a batch of fewer than 16 units per compute unit, a unit longer than two
  * pieces is cut into pieces (batch bytes / 16 / compute units, at least

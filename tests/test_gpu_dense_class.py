@@ -1,7 +1,7 @@
-"""Units of a handful of byte values in no particular order ("dense": every 4-byte key has
-hundreds of earlier occurrences) are found on the device and searched the reference's way
+"""Units carried by a few byte values, or made of short runs ("dense": every 4-byte key has
+hundreds of earlier occurrences), are found on the device and searched the reference's way
 (src/rawdeflate.js:370-395): their size is then within the bar of the reference's, which the
-bounded default search misses by 3-34 %.  Everything else must not be touched by the pass."""
+bounded default search misses by 3-47 %.  Everything else must not be touched by the pass."""
 import numpy as np
 import pytest
 
@@ -47,6 +47,50 @@ def test_small_alphabets_meet_the_bar(z, ctype):
         z._native.set_dense_search()
     assert plain[dense[0]] > 1.05 * sizes[dense[0]]
     assert all(plain[i] == sizes[i] for i in range(len(datas)) if i not in dense or len(np.unique(datas[i])) > 6)
+
+
+def _families():
+    rng = np.random.default_rng(2024)
+    n = 65536
+
+    def runs_of(k, maxlen):
+        parts, total = [], 0
+        while total < n:
+            m = int(rng.integers(1, maxlen + 1))
+            parts.append(np.full(m, (int(rng.integers(0, k)) * 37 + 1) & 255, dtype=np.uint8))
+            total += m
+        return np.concatenate(parts)[:n]
+
+    def markov(k, stay):
+        keep = rng.random(n) < stay
+        nxt = rng.integers(0, k, n).astype(np.uint8)
+        out = np.empty(n, dtype=np.uint8)
+        v = 0
+        for i in range(n):
+            if not keep[i]:
+                v = nxt[i]
+            out[i] = v
+        return out
+
+    return {
+        "geometric p=.5": np.minimum(rng.geometric(0.5, n) - 1, 255).astype(np.uint8),
+        "two values 90:10": (rng.random(n) < 0.1).astype(np.uint8),
+        "eight values, skewed": rng.choice(8, n, p=[0.6, 0.2, 0.08, 0.05, 0.03, 0.02, 0.01, 0.01]).astype(np.uint8),
+        "markov 4 stay .8": markov(4, 0.8),
+        "runs <= 8 of 3": runs_of(3, 8),
+        "runs <= 16 of 8": runs_of(8, 16),
+        "runs <= 64 of 4": runs_of(4, 64),
+        "16-bit samples below 6": np.stack([rng.integers(0, 6, n // 2).astype(np.uint8), np.zeros(n // 2, dtype=np.uint8)], 1).reshape(-1),
+    }
+
+
+@pytest.mark.parametrize("ctype", [1, 2])
+def test_skewed_alphabets_and_short_runs_meet_the_bar(z, ctype):
+    fam = _families()
+    datas = [np.ascontiguousarray(v) for v in fam.values()]
+    sizes = _sizes(z, datas, ctype)
+    ratios = {k: s / len(zo.rawdeflate(d, ctype)) for k, d, s in zip(fam, datas, sizes)}
+    assert max(ratios.values()) <= RATIO_BAR, ratios
 
 
 def test_lazy_is_the_callers_own_in_the_second_search(z):

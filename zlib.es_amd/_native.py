@@ -197,11 +197,11 @@ def set_split(piece_bytes):
     _check(lib().zgpu_set_split(piece_bytes), "zgpu_set_split")
 
 
-DEFAULT_DENSE_CHAIN = 1024
+DEFAULT_DENSE_CHAIN = 2048
 
 
 def set_dense_search(max_chain=DEFAULT_DENSE_CHAIN):
-    """Chain budget of the second, reference-like search that units of a handful of byte values get
+    """Chain budget of the second, reference-like search that units carried by a few byte values get
     (0 = no such pass); without arguments back to the default."""
     _check(lib().zgpu_set_dense_search(max_chain), "zgpu_set_dense_search")
 

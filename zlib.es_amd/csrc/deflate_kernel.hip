@@ -2352,44 +2352,57 @@ zgpu_emit_slots_kernel(EParams P) {
     emit_units<256, false>(P, lds);
 }
 
-// ---- content class of a unit: "dense" = a handful of byte values in no particular order ----
+// ---- content class of a unit: "dense" = few byte values carry the unit, or it is made of short runs ----
 // In such data every 4-byte key has hundreds to thousands of earlier occurrences and the longest of them
 // is a few bytes longer than the longest of the nearest eight, at *every* position: the bounded walk of
-// the search kernel leaves 3-30 % of size against the reference's exhaustive one (src/rawdeflate.js:370-395),
+// the search kernel leaves 3-47 % of size against the reference's exhaustive one (src/rawdeflate.js:370-395),
 // where on other data it leaves nothing.  Units of that class are searched again by the thorough kernel
 // variant over the list written here (the second search replaces the tokens of the first).
-// One wave per unit: ZGPU_CLS_CHUNKS chunks of 64 bytes spread evenly over the unit; dense = at most
-// ZGPU_CLS_VALUES distinct byte values among them, and fewer than three in four bytes equal to their successor
-// (runs have few values too, but their long matches are the first candidates of their chains).
-#define ZGPU_CLS_CHUNKS 16
-#define ZGPU_CLS_VALUES 6
+// One wave per unit looks at ZGPU_CLS_CHUNKS chunks of 64 bytes spread evenly over the unit:
+//   * the chance that two of the sampled bytes are equal (sum of squared counts) is at least 0.155 --
+//     what six equally likely values give; seven give 0.143, text 0.05-0.08, which the default search
+//     serves within the bar -- or at least half of the sampled bytes equal their successor (runs of any
+//     number of values);
+//   * and fewer than 45 % of the chunks are one byte value throughout: runs of hundreds of bytes reach
+//     the maximum match length at the first candidates of their chains and need no second search (with
+//     run lengths up to 512 the share is 0.77 +- 0.07, up to 128 it is 0.25 +- 0.08).
+#define ZGPU_CLS_CHUNKS 32
 #define ZGPU_CLS_MIN_BYTES 4096u
+#define ZGPU_CLS_SAMPLES (64u * ZGPU_CLS_CHUNKS)
 extern "C" __global__ void __launch_bounds__(256)
 zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_first, uint32_t unit_end,
                      uint32_t *dense_list, uint32_t *dense_count) {
-    __shared__ uint8_t seen[4][256];
+    __shared__ uint32_t count[4][256];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const uint32_t u = unit_first + blockIdx.x * 4u + w;
-    for (int i = 0; i < 4; ++i) seen[w][lane * 4 + i] = 0;
+    for (int i = 0; i < 4; ++i) count[w][i * 64 + lane] = 0;
     __syncthreads();
     const uint64_t uo = u < unit_end ? in_off[u] : 0;
     const uint64_t un = u < unit_end ? in_off[u + 1] - uo : 0;
     const bool live = un >= ZGPU_CLS_MIN_BYTES;  // uniform per wave; a unit has less than 4 GiB (ZGPU_MAX_UNIT_BYTES)
-    uint32_t equal = 0;
+    uint32_t one_value = 0, equal = 0;
     if (live) {
         const uint32_t n = (uint32_t)un, stride = (n - 65u) / (ZGPU_CLS_CHUNKS - 1);
         const uint8_t *src = in + uo;
         for (uint32_t c = 0; c < ZGPU_CLS_CHUNKS; ++c) {
-            const uint32_t at = c * stride + lane;  // at + 1 <= 15 * stride + 64 <= n - 1
+            const uint32_t at = c * stride + lane;  // at + 1 <= (chunks - 1) * stride + 64 <= n - 1
             const uint8_t b0 = src[at], b1 = src[at + 1];
-            seen[w][b0] = 1;
-            equal += (uint32_t)__builtin_popcountll(__ballot(b0 == b1));
+            atomicAdd(&count[w][b0], 1u);
+            const unsigned long long same = __ballot(b0 == b1);
+            one_value += same == ~0ull;
+            equal += (uint32_t)__builtin_popcountll(same);
         }
     }
     __syncthreads();
-    uint32_t values = 0;
-    for (int i = 0; i < 4; ++i) values += (uint32_t)__builtin_popcountll(__ballot(seen[w][i * 64 + lane] != 0));
-    if (live && lane == 0 && values <= ZGPU_CLS_VALUES && equal * 4u < 3u * 64u * ZGPU_CLS_CHUNKS)
+    uint32_t squares = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t c = count[w][i * 64 + lane];
+        squares += c * c;
+    }
+    for (int d = 32; d; d >>= 1) squares += __shfl_xor(squares, d);
+    const bool few_values = squares * 200ull >= 31ull * ZGPU_CLS_SAMPLES * ZGPU_CLS_SAMPLES;  // 0.155
+    const bool short_runs = equal * 2u >= ZGPU_CLS_SAMPLES;
+    if (live && lane == 0 && (few_values || short_runs) && one_value * 100u < 45u * ZGPU_CLS_CHUNKS)
         dense_list[atomicAdd(dense_count, 1u)] = u;
 }
 
