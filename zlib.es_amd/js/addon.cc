@@ -312,6 +312,9 @@ napi_value DeflateBatch(napi_env env, napi_callback_info info) {
     // one ArrayBuffer (`buffer`) and the end of the last stream (`end`)
     const uint32_t *gaps = nullptr;
     double tail = 0;
+    uint8_t *own_out = nullptr;
+    size_t own_cap = 0, own_at = 0;
+    napi_value own_ab = nullptr;
     if (argc >= 7) {
         bool is_ta = false;
         if (napi_is_typedarray(env, argv[6], &is_ta) == napi_ok && is_ta) {
@@ -320,13 +323,22 @@ napi_value DeflateBatch(napi_env env, napi_callback_info info) {
             void *gp = nullptr;
             napi_value gab;
             NAPI_OK(napi_get_typedarray_info(env, argv[6], &tt, &gl, &gp, &gab, &goff));
-            if (tt != napi_uint32_array || gl != n) {
-                napi_throw_type_error(env, nullptr, "gaps: a Uint32Array with one entry per input");
-                return nullptr;
+            if (tt == napi_uint8_array) {
+                // the caller's own output buffer (kept and reused from call to call; page-locked if it came
+                // from allocInput): the streams are written into it back to back and the outputs are views of it
+                own_out = (uint8_t *)gp;
+                own_cap = gl;
+                own_ab = gab;
+                own_at = goff;
+            } else {
+                if (tt != napi_uint32_array || gl != n) {
+                    napi_throw_type_error(env, nullptr, "gaps: a Uint32Array with one entry per input (or a Uint8Array to write into)");
+                    return nullptr;
+                }
+                gaps = (const uint32_t *)gp;
+                if (argc >= 8) NAPI_OK(napi_get_value_double(env, argv[7], &tail));
+                if (tail < 0 || tail > 4294967295.0) tail = 0;
             }
-            gaps = (const uint32_t *)gp;
-            if (argc >= 8) NAPI_OK(napi_get_value_double(env, argv[7], &tail));
-            if (tail < 0 || tail > 4294967295.0) tail = 0;
         }
     }
     double end_pos = 0;
@@ -380,7 +392,18 @@ napi_value DeflateBatch(napi_env env, napi_callback_info info) {
         // become the ArrayBuffer -- no staging of the result in page-locked memory and no second copy of it
         // (1 GiB: 17 -> 25-30 GB/s through Node).
         bool one_step_done = false;
-        if (!gaps && in_off[n] >= (32u << 20) && !getenv("ZGPU_NO_HUGE_OUTPUT")) {
+        if (own_out) {
+            rc = g.deflate_batch(src, in_off.data(), n, ctype, lazy, flags, own_out, own_cap, out_off.data(),
+                                 want_crc ? crc.data() : nullptr, want_adler ? adler.data() : nullptr);
+            if (rc) return throw_zgpu(env, "zgpu_deflate_batch", rc);
+            if (timing) t_call = now_ms();
+            for (uint32_t i = 0; i < n; ++i) {
+                napi_value ta;
+                NAPI_OK(napi_create_typedarray(env, napi_uint8_array, out_off[i + 1] - out_off[i], own_ab, own_at + out_off[i], &ta));
+                NAPI_OK(napi_set_element(env, outs, i, ta));
+            }
+            one_step_done = true;
+        } else if (!gaps && in_off[n] >= (32u << 20) && !getenv("ZGPU_NO_HUGE_OUTPUT")) {
             uint64_t bound = 64;
             for (uint32_t i = 0; i < n; ++i) bound += g.bound(in_off[i + 1] - in_off[i]) + 48;
             void *base = nullptr;

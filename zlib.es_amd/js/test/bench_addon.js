@@ -34,6 +34,9 @@ time('compressBatch, 16384 x 64 KiB views of one buffer', n * ub, () => Zlib.Raw
 	const lviews = [];
 	for (let i = 0; i < n; ++i) lviews.push(locked.subarray(i * ub, (i + 1) * ub));
 	time('compressBatch, 16384 x 64 KiB views of one allocInput buffer', n * ub, () => Zlib.RawDeflate.compressBatch(lviews, { compressionType: 2 }));
+	// ... and the output into a page-locked buffer the caller keeps from call to call
+	const out = allocInput(n * ub * 3 / 4);
+	time('compressBatch, allocInput buffer in, kept allocInput buffer out', n * ub, () => Zlib.RawDeflate.compressBatch(lviews, { compressionType: 2, output: out }));
 }
 time('compressBatch, 1024 separate 64 KiB buffers', copies.length * ub, () => Zlib.RawDeflate.compressBatch(copies, { compressionType: 2 }));
 time('deflateChunked, 1 GiB in 1 MiB chunks', n * ub, () => deflateChunked(big, { chunkSize: 1 << 20 }));

@@ -316,6 +316,19 @@ it('allocInput: page-locked inputs and the one-step path give the bytes of ordin
 	// below that size the two-step path runs: same bytes
 	const small = Zlib.RawDeflate.compressBatch(cut(plain).slice(0, 8), { compressionType: CT.DYNAMIC });
 	for (let i = 0; i < 8; ++i) assert.ok(H.equal(small[i], a[i]), 'two-step unit ' + i);
+	// the caller's own output buffer (page-locked or not, with an offset): views of it, same bytes; too small throws
+	for (const mk of [(k) => G.allocInput(k), (k) => new Uint8Array(k + 24).subarray(24)]) {
+		const out = mk(n);
+		const c = Zlib.RawDeflate.compressBatch(cut(locked), { compressionType: CT.DYNAMIC, output: out });
+		assert.strictEqual(c.length, a.length);
+		assert.strictEqual(c[0].buffer, out.buffer);
+		assert.strictEqual(c[0].byteOffset, out.byteOffset);
+		for (let i = 0; i < a.length; ++i) assert.ok(H.equal(a[i], c[i]), 'own buffer, unit ' + i);
+		const again = Zlib.RawDeflate.compressBatch(cut(plain).slice(0, 8), { compressionType: CT.DYNAMIC, output: out });
+		for (let i = 0; i < 8; ++i) assert.ok(H.equal(again[i], a[i]), 'own buffer again, unit ' + i);
+	}
+	assert.throws(() => Zlib.RawDeflate.compressBatch(cut(plain), { compressionType: CT.DYNAMIC, output: new Uint8Array(1000) }), /output/);
+	assert.throws(() => Zlib.RawDeflate.compressBatch(cut(plain), { compressionType: CT.DYNAMIC, output: [1, 2] }), TypeError);
 	G.addon.hostTrim();
 });
 

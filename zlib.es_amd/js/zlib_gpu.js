@@ -155,10 +155,18 @@ class RawDeflate {
 	}
 	// One engine call for many independent inputs: what the per-file loop of
 	// Zip.compress() (src/zip.js:119-137) becomes.
+	// opt_params.output (not in the reference): a Uint8Array the streams are written into back to back --
+	// the returned arrays are then views of it, valid until the caller reuses it.  A caller that compresses
+	// batch after batch keeps one such buffer (from allocInput: page-locked) instead of getting a new
+	// ArrayBuffer of fresh pages per call; too small a buffer throws.
 	static compressBatch(inputs, opt_params) {
 		const o = opt_params || {};
 		const ct = typeof o.compressionType === 'number' ? o.compressionType : RawDeflate.CompressionType.DYNAMIC;
 		if (ct !== 0 && ct !== 1 && ct !== 2) throw 'invalid compression type';
+		if (o.output !== undefined) {
+			if (!(o.output instanceof Uint8Array)) throw new TypeError('output: a Uint8Array');
+			return addon.deflateBatch(inputs.map(asU8), ct, o.lazy | 0, F_FINAL_EACH, false, false, o.output).outputs;
+		}
 		return addon.deflateBatch(inputs.map(asU8), ct, o.lazy | 0, F_FINAL_EACH, false, false).outputs;
 	}
 }
