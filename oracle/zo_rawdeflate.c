@@ -208,6 +208,9 @@ static void write_match(zo_lz *z, int len, int dist, int offset) {
     z->prev_valid = 0;
 }
 
+#ifndef ZO_WINDOW /* diagnostic builds may shorten the window; the reference's is 32 KiB, :325-327 */
+#define ZO_WINDOW 0x8000
+#endif
 size_t zo_lz77(const uint8_t *in, size_t n, int lazy, uint16_t *tokens, uint32_t *freqs_litlen,
                uint32_t *freqs_dist) {
     uint32_t fl_local[286], fd_local[30];
@@ -249,7 +252,7 @@ size_t zo_lz77(const uint8_t *in, size_t n, int lazy, uint16_t *tokens, uint32_t
          * wins (ties keep the nearest), stop at 258; window :325-327. */
         int best_len = 0, best_dist = 0;
         size_t maxlen = n - position < 258 ? n - position : 258;
-        for (int32_t c = head[h]; c >= 0 && position - (size_t)c <= 0x8000; c = prev[c]) {
+        for (int32_t c = head[h]; c >= 0 && position - (size_t)c <= ZO_WINDOW; c = prev[c]) {
             const uint8_t *a = in + c, *b = in + position;
             if (a[0] != b[0] || a[1] != b[1] || a[2] != b[2]) continue; /* other key */
             if (best_len >= 3) {
@@ -264,6 +267,9 @@ size_t zo_lz77(const uint8_t *in, size_t n, int lazy, uint16_t *tokens, uint32_t
             }
             if (l == 258) break;
         }
+#ifdef ZO_MIN_MATCH /* diagnostic builds only: what the reference would make of a longer shortest match */
+        if (best_len < ZO_MIN_MATCH) best_len = 0;
+#endif
         if (best_len > 0) { /* :337-347 */
             if (z.prev_valid) {
                 if (z.prev_len < best_len) {

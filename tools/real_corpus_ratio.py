@@ -42,13 +42,16 @@ for name, pattern, limit in SETS:
     step = max(1, len(units) // 48)
     sample = units[::step]
     for ct in (2, 1):
-        ref = sum(len(zo.rawdeflate(u, ct, 0)) for u in sample)
+        refs = [len(zo.rawdeflate(u, ct, 0)) for u in sample]
+        ref = sum(refs)
         res = []
         for chain in ([int(a) for a in sys.argv[1:]] or [z._native.DEFAULT_MAX_CHAIN]):
             z.set_search(chain)
             outs, _, _ = z.deflate_batch(sample, ct, 0)
             assert all(zo.inflate_raw(o, u.size) == u.tobytes() for o, u in zip(outs, sample))
-            res.append("chain %d: %.4f" % (chain, sum(len(o) for o in outs) / ref))
+            per = [len(o) / r for o, r in zip(outs, refs)]
+            res.append("chain %d: %.4f (worst unit %.3f, %d above 1.03)" % (
+                chain, sum(len(o) for o in outs) / ref, max(per), sum(x > 1.03 for x in per)))
         z.set_search()
         print("%-17s %4d units of 64 KiB, ctype %d, gpu/ref: %s (ref out/in %.3f)" % (
             name, len(sample), ct, ", ".join(res), ref / (len(sample) * 65536)), flush=True)

@@ -58,6 +58,9 @@ constexpr uint32_t WMASK = 0x7fff;  // chain slots (32 Ki positions)
 #ifndef ZGPU_LAG_FULL
 #define ZGPU_LAG_FULL 54
 #endif
+#ifndef ZGPU_FAR_BLOCK
+#define ZGPU_FAR_BLOCK 1
+#endif
 #ifndef ZGPU_PEND_FULL
 #define ZGPU_PEND_FULL 3
 #endif
@@ -93,6 +96,12 @@ struct CfgFull {  // 32 KiB window, one workgroup per CU
     static constexpr int WG_PER_CU = 1;
     static constexpr uint32_t RING = 65536, CHAIN = 32768, HBITS = 13, NSLOT = 64, NSLOT_E = 128, LAG = ZGPU_LAG_FULL;
     static constexpr int PEND = ZGPU_PEND_FULL;
+    // The ring is refilled an eighth at a time, so that it still holds the 32 KiB behind the oldest item in
+    // flight while the newest bytes come in: matches reach as far back as the format allows.  (The chain
+    // links of positions more than CHAIN - span of the items in flight back are already overwritten -- such a
+    // position is still found as somebody's nearest earlier occurrence, but nothing beyond it.)
+    static constexpr uint32_t REFILL = RING / 8;
+    static constexpr bool FULL_DISTANCE = true;
 };
 #ifndef ZGPU_HALF_HBITS
 #define ZGPU_HALF_HBITS 11
@@ -103,6 +112,8 @@ struct CfgHalf {  // units of at most 16 KiB: two workgroups per CU, 16 Ki chain
     static constexpr int WG_PER_CU = ZGPU_HALF_WGS;
     static constexpr uint32_t RING = 32768, CHAIN = 16384, HBITS = ZGPU_HALF_HBITS, NSLOT = 32, NSLOT_E = 64, LAG = ZGPU_LAG_HALF;
     static constexpr int PEND = 2;  // 64 registers per lane: a third pending item would be paid in spills
+    static constexpr uint32_t REFILL = RING / 4;
+    static constexpr bool FULL_DISTANCE = false;  // the units fit the window as it is
 };
 
 struct CfgQuarter {  // units of at most 4 KiB: four workgroups of eight waves per CU, 8 Ki chain slots
@@ -110,6 +121,8 @@ struct CfgQuarter {  // units of at most 4 KiB: four workgroups of eight waves p
     static constexpr int WG_PER_CU = 4;
     static constexpr uint32_t RING = 16384, CHAIN = 8192, HBITS = 10, NSLOT = 16, NSLOT_E = 32, LAG = ZGPU_LAG_QUARTER;
     static constexpr int PEND = 2;
+    static constexpr uint32_t REFILL = RING / 4;
+    static constexpr bool FULL_DISTANCE = false;
 };
 
 constexpr uint32_t huf_scratch_bytes(uint32_t cap) { return 17 * cap + 128; }  // see HufS
@@ -638,8 +651,11 @@ __device__ __forceinline__ void search_units(const Params &P) {
     // item, and where items differ much in length (deep walks) a wave with room for a third goes on working
     // (bench with the deep walk on: 83.2 -> 81.9 ms; four are slower again)
     constexpr int PEND = C::PEND;
-    constexpr uint32_t REFILL = RING / 4;  // ring refill granule
-    constexpr uint32_t MAXDIST = C::CHAIN - 64 * (LAG + AHEAD) - 128;  // window minus the span of in-flight items
+    constexpr uint32_t REFILL = C::REFILL;  // ring refill granule
+    constexpr uint32_t LINKDIST = C::CHAIN - 64 * (LAG + AHEAD) - 128;  // chain slots minus the span of in-flight items
+    // how far back a match may lie: the bytes must still be in the ring for the oldest item in flight
+    constexpr uint32_t RINGDIST = RING - 64 * LAG - 2 * REFILL;
+    constexpr uint32_t MAXDIST = !C::FULL_DISTANCE ? LINKDIST : RINGDIST < 32768u ? RINGDIST : 32768u;
     constexpr uint32_t L_RING = 0, L_PREV = L_RING + RING + RING_PAD, L_HEAD = L_PREV + 2 * C::CHAIN,
                        L_FL = L_HEAD + (2u << HBITS), L_FD = L_FL + 288 * 4, L_MISC = L_FD + 32 * 4,
                        L_SCR = L_MISC + 64 * 4;
@@ -1095,7 +1111,10 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 uint32_t best_len = 0, best_dist = 0;
                 if (k >= prime_items) {  // priming items are only inserted
                     const uint32_t maxlen = p < n ? ((n - p) < 258u ? (n - p) : 258u) : 0u;
-                    const uint32_t limit = p < MAXDIST ? p : MAXDIST;
+                    // how far back the links can be followed, and how far back a match may lie (the same number
+                    // except in the variant whose ring holds more than its chain slots reach)
+                    const uint32_t limit = p < LINKDIST ? p : LINKDIST;
+                    const uint32_t flimit = p < MAXDIST ? p : MAXDIST;
                     const uint32_t pi = p & (RING - 1);
                     uint32_t blen = 2;
                     uint32_t c = 0, last = 0xffffu;  // the walk's next candidate and last distance (last = 0xffff: walk over)
@@ -1149,7 +1168,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             if (open) run += ext;
                         }
                         if (run > maxlen) run = maxlen;
-                        if (run >= 3 && d <= limit && (run > blen || (run == blen && d < best_dist))) {
+                        if (run >= 3 && d <= flimit && (run > blen || (run == blen && d < best_dist))) {
                             blen = run;
                             best_dist = d;
                         }
@@ -1242,6 +1261,31 @@ __device__ __forceinline__ void search_units(const Params &P) {
                                 if (!THOROUGH && budget == walk_budget - 2 && !__ballot(blen >= 4u)) break;
                                 if (!candidate()) break;
                             }
+                            if constexpr (C::FULL_DISTANCE && ZGPU_FAR_BLOCK) {
+                                // A walk that ran out of the links' reach stands at a candidate that is still worth a
+                                // look: it is the nearest earlier occurrence behind the last one examined (that one's
+                                // link slot is intact), and its bytes are in the ring.  Its own slot may already belong
+                                // to a position one chain table further on, so nothing is followed from it.  This is
+                                // what finds the copy of a file's preamble in the file before it, 29-32 KiB back.
+                                const uint32_t fdist = (p - c) & 0xffffu;
+                                const bool fgo = fdist > limit && fdist <= flimit && blen < cmpmax;
+                                // (where a handful of the item's positions stand at such a candidate, not one or two:
+                                // a copy that far back is found by several of them and shared with the others below,
+                                // while text's scattered far candidates, looked at one by one, cost the walk 4 % for
+                                // a tenth of a per cent of size)
+                                if (__builtin_popcountll(__ballot(fgo)) >= 16) {
+                                    if (fgo) {
+                                        const uint32_t ci = c & (RING - 1);
+                                        uint32_t len = mlen16(own, ld16(ring, ci));
+                                        if (len == 16 && cmpmax > 16) len = 16 + mlen16(ld16(ring, pi + 16), ld16(ring, ci + 16));
+                                        if (len > cmpmax) len = cmpmax;
+                                        if (len > blen) {
+                                            blen = len;
+                                            best_dist = fdist;
+                                        }
+                                    }
+                                }
+                            }
                         }
                     }
                     PH_END(12);
@@ -1263,6 +1307,24 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             const uint32_t d = rl(offer, (uint32_t)__builtin_ctzll(todo));  // a uniform lane: v_readlane, no LDS
                             score_distance(d);
                             todo &= ~__ballot(offer == d);
+                        }
+                        // Three-byte matches at the strides of small records.  The chains are keyed by four
+                        // bytes, so a match of exactly three bytes is found only by accident -- and arrays of
+                        // 32-bit numbers that differ in their low byte (symbol and hash tables, offsets,
+                        // relocations) consist of nothing else: the reference codes each element as one literal
+                        // and one three-byte match four bytes back (src/rawdeflate.js:370-395 keys on three
+                        // bytes), which is a third less than four literals.  Whether the three bytes at a
+                        // position repeat 4, 8 or 12 bytes further on is seen in the 16 bytes each lane holds;
+                        // where enough positions without a match would gain one, that distance is scored for the
+                        // whole item.
+                        const uint32_t x4 = (own.x ^ own.y) << 8, x8 = (own.x ^ own.z) << 8, x12 = (own.x ^ own.w) << 8;
+                        uint32_t xm = x4 < x8 ? x4 : x8;
+                        xm = xm < x12 ? xm : x12;
+                        if (__builtin_popcountll(__ballot(xm == 0u)) >= 6) {
+                            const unsigned long long need = __ballot(p + 3u <= n && blen < 4u);
+                            if (__builtin_popcountll((__ballot(x4 == 0u) << 4) & need) >= 4) score_distance(4u);
+                            if (__builtin_popcountll((__ballot(x8 == 0u) << 8) & need) >= 4) score_distance(8u);
+                            if (__builtin_popcountll((__ballot(x12 == 0u) << 12) & need) >= 4) score_distance(12u);
                         }
                     }
                     PH_END(13);
@@ -2371,7 +2433,7 @@ zgpu_emit_slots_kernel(EParams P) {
 #define ZGPU_CLS_SAMPLES (64u * ZGPU_CLS_CHUNKS)
 extern "C" __global__ void __launch_bounds__(256)
 zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_first, uint32_t unit_end,
-                     uint32_t *dense_list, uint32_t *dense_count) {
+                     uint32_t *dense_list, uint32_t list_stride, uint32_t *dense_count) {
     __shared__ uint32_t count[4][256];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const uint32_t u = unit_first + blockIdx.x * 4u + w;
@@ -2400,10 +2462,15 @@ zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_fi
         squares += c * c;
     }
     for (int d = 32; d; d >>= 1) squares += __shfl_xor(squares, d);
+    uint32_t values = 0;
+    for (int i = 0; i < 4; ++i) values += (uint32_t)__builtin_popcountll(__ballot(count[w][i * 64 + lane] != 0u));
     const bool few_values = squares * 200ull >= 31ull * ZGPU_CLS_SAMPLES * ZGPU_CLS_SAMPLES;  // 0.155
     const bool short_runs = equal * 2u >= ZGPU_CLS_SAMPLES;
-    if (live && lane == 0 && (few_values || short_runs) && one_value * 100u < 45u * ZGPU_CLS_CHUNKS)
-        dense_list[atomicAdd(dense_count, 1u)] = u;
+    if (live && lane == 0 && (few_values || short_runs) && one_value * 100u < 45u * ZGPU_CLS_CHUNKS) {
+        // two lists: units of at most six byte values are parsed greedily (see the launches)
+        const uint32_t which = values <= 6u ? 0u : 1u;
+        dense_list[which * list_stride + atomicAdd(dense_count + 2u * which, 1u)] = u;
+    }
 }
 
 // ---- stored blocks (CompressionType.NONE; makeNocompressBlock rawdeflate.js:131-153)
