@@ -116,7 +116,14 @@ int zgpu_last_hip_error(void);
  * length and the longest wins (the nearest among equals): (32768, 258) is the
  * reference's exhaustive search, two orders of magnitude slower than the
  * default; (8, 258) costs about 40 % of the speed and makes highly repetitive
- * input up to 15 % smaller. */
+ * input up to 15 % smaller.
+ * Whatever the settings, a match may lie up to 32768 bytes back, as the format
+ * allows (units above 16 KiB; the chains are followed about 29,000 bytes back
+ * and the first candidate beyond that is still examined), and matches of three
+ * bytes -- the chains are keyed by four -- are found where they repeat 4, 8 or
+ * 12 bytes back (arrays of small numbers) or where a longer candidate happens
+ * to lead to them; the reference's other three-byte matches are not (up to
+ * 9 % of size under FIXED on tables of 16-bit values in 32-bit slots). */
 int zgpu_set_search(int max_chain, int nice_length);
 /* Long matches.  A position whose match reaches the 32-byte compare length and
  * does not merely continue its predecessor's match is where a parse may need
@@ -157,9 +164,12 @@ int zgpu_set_long_match(int deep_chain, int probe_fans);
  * one value throughout (runs of hundreds of bytes need nothing more than the
  * default search).  The units of that class are searched the reference's way
  * (src/rawdeflate.js:370-395: every candidate compared to its full length, the
- * longest wins, the nearest among equals; the parse defers a match only below
- * the caller's own `lazy`), along at most max_chain candidates per position
- * (0..32768, default 2048; 0 = no such pass).  Such units then come out at
+ * longest wins, the nearest among equals), along at most max_chain candidates
+ * per position (0..32768, default 2048; 0 = no such pass).  Their parse follows
+ * the content: units of at most six byte values, and every such unit under
+ * DYNAMIC, defer a match only below the caller's own `lazy` (0: the reference's
+ * greedy parse); the others, under FIXED, keep the look-ahead of the default
+ * parse (see zgpu_set_min_lazy).  Such units then come out at
  * 0.99-1.02 x the reference's size in both modes (1024: up to 1.03 x, 4096: up
  * to 1.01 x, at half and twice the time) and take 3-130 ms per 64 KiB on their
  * compute unit instead of 0.4 -- 0.1-5 GB/s per GPU, where one CPU core runs

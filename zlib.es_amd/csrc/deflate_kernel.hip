@@ -2446,9 +2446,21 @@ zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_fi
     if (live) {
         const uint32_t n = (uint32_t)un, stride = (n - 65u) / (ZGPU_CLS_CHUNKS - 1);
         const uint8_t *src = in + uo;
+        // all samples are requested before the first is looked at (the loop below would otherwise pay one
+        // memory round trip per chunk: 0.28 -> 0.18 ms per 32768 small files); lane l reads byte l of the chunk,
+        // lane 63 also the byte behind it
+        uint8_t b[ZGPU_CLS_CHUNKS], last[ZGPU_CLS_CHUNKS];
+#pragma unroll
         for (uint32_t c = 0; c < ZGPU_CLS_CHUNKS; ++c) {
             const uint32_t at = c * stride + lane;  // at + 1 <= (chunks - 1) * stride + 64 <= n - 1
-            const uint8_t b0 = src[at], b1 = src[at + 1];
+            b[c] = src[at];
+            last[c] = lane == 63u ? src[at + 1] : (uint8_t)0;
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < ZGPU_CLS_CHUNKS; ++c) {
+            const uint32_t b0 = b[c];
+            const uint32_t nb = (uint32_t)__shfl_down((int)b0, 1);
+            const uint32_t b1 = lane == 63u ? (uint32_t)last[c] : nb;
             atomicAdd(&count[w][b0], 1u);
             const unsigned long long same = __ballot(b0 == b1);
             one_value += same == ~0ull;
