@@ -1267,21 +1267,24 @@ __device__ __forceinline__ void search_units(const Params &P) {
                                 // link slot is intact), and its bytes are in the ring.  Its own slot may already belong
                                 // to a position one chain table further on, so nothing is followed from it.  This is
                                 // what finds the copy of a file's preamble in the file before it, 29-32 KiB back.
-                                const uint32_t fdist = (p - c) & 0xffffu;
-                                const bool fgo = fdist > limit && fdist <= flimit && blen < cmpmax;
-                                // (where a handful of the item's positions stand at such a candidate, not one or two:
-                                // a copy that far back is found by several of them and shared with the others below,
-                                // while text's scattered far candidates, looked at one by one, cost the walk 4 % for
-                                // a tenth of a per cent of size)
-                                if (__builtin_popcountll(__ballot(fgo)) >= 16) {
-                                    if (fgo) {
-                                        const uint32_t ci = c & (RING - 1);
-                                        uint32_t len = mlen16(own, ld16(ring, ci));
-                                        if (len == 16 && cmpmax > 16) len = 16 + mlen16(ld16(ring, pi + 16), ld16(ring, ci + 16));
-                                        if (len > cmpmax) len = cmpmax;
-                                        if (len > blen) {
-                                            blen = len;
-                                            best_dist = fdist;
+                                // An item in the unit's first 29 KB has nothing that far behind it (a scalar test).  Else
+                                // the candidate is looked at where a good part of the item's positions stand at one, not
+                                // one or two: a copy that far back is found by several of them and shared with the others
+                                // below, while text's scattered far candidates, looked at one by one, cost the walk 4 %
+                                // for a tenth of a per cent of size.
+                                if (p0 + 63u > LINKDIST) {
+                                    const uint32_t fdist = (p - c) & 0xffffu;
+                                    const bool fgo = fdist > limit && fdist <= flimit && blen < cmpmax;
+                                    if (__builtin_popcountll(__ballot(fgo)) >= 16) {
+                                        if (fgo) {
+                                            const uint32_t ci = c & (RING - 1);
+                                            uint32_t len = mlen16(own, ld16(ring, ci));
+                                            if (len == 16 && cmpmax > 16) len = 16 + mlen16(ld16(ring, pi + 16), ld16(ring, ci + 16));
+                                            if (len > cmpmax) len = cmpmax;
+                                            if (len > blen) {
+                                                blen = len;
+                                                best_dist = fdist;
+                                            }
                                         }
                                     }
                                 }
