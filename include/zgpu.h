@@ -165,11 +165,13 @@ int zgpu_set_long_match(int deep_chain, int probe_fans);
  * default search).  The units of that class are searched the reference's way
  * (src/rawdeflate.js:370-395: every candidate compared to its full length, the
  * longest wins, the nearest among equals), along at most max_chain candidates
- * per position (0..32768, default 2048; 0 = no such pass).  Their parse follows
- * the content: units of at most six byte values, and every such unit under
- * DYNAMIC, defer a match only below the caller's own `lazy` (0: the reference's
- * greedy parse); the others, under FIXED, keep the look-ahead of the default
- * parse (see zgpu_set_min_lazy).  Such units then come out at
+ * per position (0..32768, default 2048; 0 = no such pass; units of more than
+ * six byte values that are not made of short runs get an eighth of it, which
+ * is as much as they need).  Their parse follows the content: units of at most
+ * six byte values, and every such unit under DYNAMIC, defer a match only below
+ * the caller's own `lazy` (0: the reference's greedy parse); the others, under
+ * FIXED, keep the look-ahead of the default parse (see zgpu_set_min_lazy).
+ * Such units then come out at
  * 0.99-1.02 x the reference's size in both modes (1024: up to 1.03 x, 4096: up
  * to 1.01 x, at half and twice the time) and take 3-130 ms per 64 KiB on their
  * compute unit instead of 0.4 -- 0.1-5 GB/s per GPU, where one CPU core runs

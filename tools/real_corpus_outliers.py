@@ -38,17 +38,33 @@ def stats(d, chunks=32):
 
 SETS = [("shared libraries", "/usr/lib/x86_64-linux-gnu/*.so*", int(os.environ.get("LIMIT", 16 << 20))),
         ("C headers", "/usr/include/**/*.h", 8 << 20)]
+if "SETS" in os.environ:  # "name=glob,name=glob": other files of the image, 8 MiB of each
+    SETS = [(kv.split("=")[0], kv.split("=")[1], int(os.environ.get("LIMIT", 8 << 20))) for kv in os.environ["SETS"].split(",")]
+if "DENSE" in os.environ:  # chain budget of the dense-class pass
+    z._native.set_dense_search(int(os.environ["DENSE"]))
+BRIEF = "BRIEF" in os.environ  # counts and the worst units only, at the default settings
 SETTINGS = [("default", None), ("chain 32", (32, 32)), ("thorough 8", (8, 258)), ("thorough 2048", (2048, 258)),
             ("exhaustive", (32768, 258))]
 for name, pattern, limit in SETS:
     d = corpus(pattern, limit)
     units = [d[i:i + 65536] for i in range(0, d.size - 65535, 65536)]
+    if not units:
+        print(name, "not enough data")
+        continue
     for ct in (1, 2):
         refs = [len(zo.rawdeflate(u, ct, 0)) for u in units]
         outs, _, _ = z.deflate_batch(units, ct, 0)
         bad = [i for i, (o, r) in enumerate(zip(outs, refs)) if len(o) > 1.03 * r]
-        print("%s, ctype %d: %d units, %d above 1.03" % (name, ct, len(units), len(bad)), flush=True)
+        print("%s, ctype %d: %d units, %d above 1.03, sum %.4f" % (
+            name, ct, len(units), len(bad), sum(len(o) for o in outs) / sum(refs)), flush=True)
         if not bad:
+            continue
+        if BRIEF:
+            worst = sorted(bad, key=lambda i: -len(outs[i]) / refs[i])[:4]
+            for i in worst:
+                sq, eq, one = stats(units[i])
+                print("  unit %4d ref out/in %.3f squares %.3f equal %.2f one-value %.2f | default %.3f | %s" % (
+                    i, refs[i] / 65536, sq, eq, one, len(outs[i]) / refs[i], bytes(units[i][32768:32768 + 24]).hex()), flush=True)
             continue
         sub = [units[i] for i in bad]
         cols = {}

@@ -2482,8 +2482,8 @@ zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_fi
     const bool few_values = squares * 200ull >= 31ull * ZGPU_CLS_SAMPLES * ZGPU_CLS_SAMPLES;  // 0.155
     const bool short_runs = equal * 2u >= ZGPU_CLS_SAMPLES;
     if (live && lane == 0 && (few_values || short_runs) && one_value * 100u < 45u * ZGPU_CLS_CHUNKS) {
-        // two lists: units of at most six byte values are parsed greedily (see the launches)
-        const uint32_t which = values <= 6u ? 0u : 1u;
+        // three lists (see the launches): at most six byte values; more values in short runs; more values, no runs
+        const uint32_t which = values <= 6u ? 0u : short_runs ? 1u : 2u;
         dense_list[which * list_stride + atomicAdd(dense_count + 2u * which, 1u)] = u;
     }
 }

@@ -342,8 +342,9 @@ struct zgpu_plan {
     // listed at d_list + cls_at[c]; all zero: the round is of one class (by max_bytes) and runs as a range
     struct Round { uint32_t first, end; uint64_t max_bytes; uint32_t cls_at[3] = {0, 0, 0}, cls_len[3] = {0, 0, 0}; };
     uint32_t *d_list = nullptr;
-    // units of the dense content class, found on the device when the plan runs: b_dense holds the largest
-    // round's worth of unit numbers (the tail 0xffffffff = no unit); the count is word 6 * rounds + 1 of b_counter
+    // units of the dense content class, found on the device when the plan runs: b_dense holds three lists of
+    // the largest round's worth of unit numbers each (the tail 0xffffffff = no unit); their queue heads and
+    // counts are the six words of b_counter from 6 * rounds on
     DevBuf b_dense;
     uint32_t dense_cap = 0;  // 0: the plan has no such pass
     std::vector<Round> rounds;  // units whose tokens share the token buffer at one time
@@ -666,7 +667,7 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
     ENS(p->b_status, (size_t)n_pieces * 4);
     ENS(p->b_crc, (size_t)n_units * 4);
     ENS(p->b_adler, (size_t)n_units * 4);
-    ENS(p->b_counter, (p->rounds.size() * 6 + 4) * 4);
+    ENS(p->b_counter, (p->rounds.size() * 6 + 6) * 4);
     if (p->direct) ENS(p->b_state, (size_t)n_pieces * 8);
     if (ctype != ZGPU_NONE && !p->direct) ENS(p->b_out_tmp, acc + 64);
     if (ctype != ZGPU_NONE) {
@@ -679,7 +680,7 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
     if (ctype != ZGPU_NONE && p->knobs.dense_chain > p->knobs.max_chain && p->knobs.nice <= 32) {
         for (const auto &r : p->rounds)
             if (r.end - r.first > p->dense_cap) p->dense_cap = r.end - r.first;
-        ENS(p->b_dense, (size_t)p->dense_cap * 8);  // two lists
+        ENS(p->b_dense, (size_t)p->dense_cap * 12);  // three lists
     }
     if (p->split) ENS(p->b_unit_out_off, (size_t)(n_units + 1) * 8);
     if (p->n_segs) {
@@ -1387,7 +1388,7 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
     if ((uintptr_t)d_out & 3) return ZGPU_E_ARG;  // units that share a 32-bit word with a neighbour are stitched bytewise
     hipStream_t st = (hipStream_t)stream_;
     HIPCHK(hipEventRecord(p->ev[0], st));
-    HIPCHK(hipMemsetAsync(p->d_counter(), 0, (p->rounds.size() * 6 + 4) * 4, st));
+    HIPCHK(hipMemsetAsync(p->d_counter(), 0, (p->rounds.size() * 6 + 6) * 4, st));
     if (p->direct) HIPCHK(hipMemsetAsync(p->b_state.p, 0, (size_t)p->n_pieces * 8, st));
     HIPCHK(hipEventRecord(p->ev[1], st));
     if (p->ctype == ZGPU_NONE) {
@@ -1419,8 +1420,8 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             const auto &R = p->rounds[r];
             if (p->dense_cap) {
                 // which units are of the dense class (their list starts over with every round)
-                HIPCHK(hipMemsetAsync(p->b_dense.p, 0xff, (size_t)p->dense_cap * 8, st));
-                if (r) HIPCHK(hipMemsetAsync(p->d_counter() + 6 * p->rounds.size(), 0, 16, st));
+                HIPCHK(hipMemsetAsync(p->b_dense.p, 0xff, (size_t)p->dense_cap * 12, st));
+                if (r) HIPCHK(hipMemsetAsync(p->d_counter() + 6 * p->rounds.size(), 0, 24, st));
                 hipLaunchKernelGGL(zgpu_classify_kernel, dim3((cnt + 3) / 4), dim3(256), 0, st, (const uint8_t *)d_in,
                                    p->d_in_off, first, end, p->b_dense.as<uint32_t>(), p->dense_cap,
                                    p->d_counter() + 6 * p->rounds.size() + 1);
@@ -1465,23 +1466,28 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
                 // is good enough only at 258); the tokens, counts and histograms of the first search are
                 // overwritten.  A list ends at its first 0xffffffff entry: a workgroup that draws it is done,
                 // so with no dense unit in the round these launches take a few microseconds.
-                // Two lists, two parses.  Units of at most six byte values are parsed as the caller's lazy says
-                // (0: greedily, like the reference): a literal costs them eight or nine bits and a byte of a
-                // match a fraction of one, so putting a match off for a longer one loses (two values: 1.04 x the
+                // Three lists.  (0) Units of at most six byte values are parsed as the caller's lazy says (0:
+                // greedily, like the reference): a literal costs them eight or nine bits and a byte of a match a
+                // fraction of one, so putting a match off for a longer one loses (two values: 1.04 x the
                 // reference's size under FIXED with the look-ahead, 1.00 x without; 16-bit samples below six:
-                // 1.06 x against 1.00 x).  The others keep the look-ahead of the default parse under FIXED, where
-                // a literal has its fixed price (tables of small numbers among zeros: 1.05 x without, 1.03 x
-                // with); under DYNAMIC the code lengths follow the tokens and the reference's sizes come from its
-                // greedy parse of the same matches (16-bit tables in shared libraries: 1.03-1.05 x with the
-                // look-ahead, within the bar without).
+                // 1.06 x against 1.00 x).  (1, 2) The others keep the look-ahead of the default parse under FIXED,
+                // where a literal has its fixed price (tables of small numbers among zeros: 1.05 x without,
+                // 1.03 x with); under DYNAMIC the code lengths follow the tokens and the reference's sizes come
+                // from its greedy parse of the same matches (16-bit tables in shared libraries: 1.03-1.05 x with
+                // the look-ahead, within the bar without).  (2) Of those, the units that are not made of short
+                // runs get an eighth of the chain budget: with more than six values in play and no runs a
+                // position's chain thins out quickly (skewed alphabets 1.00 x at 256 as at 2048; indented JSON
+                // that happens to fall into the class), and such a unit then costs 5 ms instead of 25; short
+                // runs of eight values need the whole budget (1.05 x at 256).
                 const int floor_lazy = p->lazy > p->knobs.min_lazy ? p->lazy : p->knobs.min_lazy;
-                for (uint32_t which = 0; which < 2; ++which) {
+                for (uint32_t which = 0; which < 3; ++which) {
                     P.unit_list = p->b_dense.as<uint32_t>() + (size_t)which * p->dense_cap;
                     P.list_len = cnt;
                     P.unit_first = 0;
                     P.unit_end = 0xffffffffu;
                     P.counter = p->d_counter() + 6 * p->rounds.size() + 2 * which;
-                    P.max_chain = p->knobs.dense_chain;
+                    P.max_chain = which == 2 ? (p->knobs.dense_chain + 7) / 8 : p->knobs.dense_chain;
+                    if (P.max_chain <= p->knobs.max_chain) P.max_chain = p->knobs.max_chain + 1;
                     P.nice = 258;
                     P.lazy = which && p->ctype == ZGPU_FIXED ? floor_lazy : p->lazy;
                     const uint32_t cus = (uint32_t)p->ds->cus;
