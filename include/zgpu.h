@@ -158,11 +158,11 @@ int zgpu_set_long_match(int deep_chain, int probe_fans);
  * up for (1.03-1.47 x the reference's size under FIXED, up to 1.29 x under
  * DYNAMIC at the default max_chain).  Every unit of at least 4 KiB is
  * therefore classified on the device before it is searched, from 32 samples of
- * 64 bytes: two sampled bytes are equal with a chance of at least 0.155 (what
- * six equally likely values give; text: 0.05-0.08) or at least half of the
- * sampled bytes equal their successor, and fewer than 45 % of the samples are
- * one value throughout (runs of hundreds of bytes need nothing more than the
- * default search).  The units of that class are searched the reference's way
+ * 64 bytes: fewer than 45 % of the samples are one value throughout (runs of
+ * hundreds of bytes need nothing more than the default search), and among the
+ * other samples two bytes are equal with a chance of at least 0.155 (what six
+ * equally likely values give; text: 0.05-0.08) or at least half of the bytes
+ * equal their successor.  The units of that class are searched the reference's way
  * (src/rawdeflate.js:370-395: every candidate compared to its full length, the
  * longest wins, the nearest among equals), along at most max_chain candidates
  * per position (0..32768, default 2048; 0 = no such pass; units of more than
@@ -173,8 +173,8 @@ int zgpu_set_long_match(int deep_chain, int probe_fans);
  * FIXED, keep the look-ahead of the default parse (see zgpu_set_min_lazy).
  * Such units then come out at
  * 0.99-1.02 x the reference's size in both modes (1024: up to 1.03 x, 4096: up
- * to 1.01 x, at half and twice the time) and take 3-130 ms per 64 KiB on their
- * compute unit instead of 0.4 -- 0.1-5 GB/s per GPU, where one CPU core runs
+ * to 1.01 x, at half and twice the time) and take 3-55 ms per 64 KiB on their
+ * compute unit instead of 0.4 -- 0.3-5 GB/s per GPU, where one CPU core runs
  * the reference's algorithm at 0.3-1.6 MB/s; other input pays the
  * classification and an empty launch, 0.2 % of its time.  The second search
  * starts when the first has finished: a batch with a few such units among

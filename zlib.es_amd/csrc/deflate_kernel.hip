@@ -1209,6 +1209,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         // bytes reads 16 more (CMP_CAP; pass 2 finds the exact length of long
                         // matches).
                         const uint32_t cmpmax = maxlen < CMP_CAP ? maxlen : CMP_CAP;
+                        uint32_t own_tail = 0;  // THOROUGH: this position's four bytes that end at offset blen
                         // one candidate of this lane's walk; false: the walk is over
                         auto candidate = [&]() -> bool {
                             const uint32_t dist = (p - c) & 0xffffu;
@@ -1219,6 +1220,25 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             last = dist;
                             const uint32_t ci = c & (RING - 1);
                             const uint32_t nxt = prevt[c & WMASK];
+                            if (THOROUGH) {
+                                // Only a longer match replaces the best so far (the walk goes from near to far and
+                                // the nearest of equals wins), and a longer one agrees with this position in the
+                                // four bytes that end at offset blen -- the reference's own first test
+                                // (src/rawdeflate.js:377-380): two dwords tell, where the full compare reads five
+                                // per 16 bytes of the best length.  Inside runs that is the difference between one
+                                // step and sixteen per candidate (every earlier position of the run matches as far
+                                // as the run goes and no further): a unit of runs of up to 128 bytes 130 -> 20 ms.
+                                // Where the bytes are independent (two or three values) some lane of 64 passes the
+                                // test at nearly every step and the wave pays for both paths: 25 -> 37 ms.
+                                if (blen >= 4u) {
+                                    const uint32_t o = ci + blen - 3u;
+                                    const uint32_t *w = (const uint32_t *)(ring + (o & (RING - 1) & ~3u));
+                                    if (__builtin_amdgcn_alignbyte(w[1], w[0], o & 3u) != own_tail) {
+                                        c = nxt;
+                                        return true;
+                                    }
+                                }
+                            }
                             uint32_t len = mlen16(own, ld16(ring, ci));
                             if (len == 16 && cmpmax > 16)
                                 len = 16 + mlen16(ld16(ring, pi + 16), ld16(ring, ci + 16));
@@ -1244,6 +1264,13 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             const bool better = len > blen;
                             blen = better ? len : blen;
                             best_dist = better ? dist : best_dist;
+                            if (THOROUGH) {
+                                if (better && blen >= 4u && blen < maxlen) {
+                                    const uint32_t o = pi + blen - 3u;
+                                    const uint32_t *w = (const uint32_t *)(ring + (o & (RING - 1) & ~3u));
+                                    own_tail = __builtin_amdgcn_alignbyte(w[1], w[0], o & 3u);
+                                }
+                            }
                             // as long as the unit allows, or as long as the caller finds nice
                             // (nice <= CMP_CAP, the default: the first capped candidate ends
                             // the walk; pass 2 finds its exact length and the long-match
@@ -2431,6 +2458,9 @@ zgpu_emit_slots_kernel(EParams P) {
 //   * and fewer than 45 % of the chunks are one byte value throughout: runs of hundreds of bytes reach
 //     the maximum match length at the first candidates of their chains and need no second search (with
 //     run lengths up to 512 the share is 0.77 +- 0.07, up to 128 it is 0.25 +- 0.08).
+// The first two are taken over the chunks that are not one value throughout: a unit that is long runs in
+// part and text for the rest has few values by count, and is not dense (the second search is at its slowest
+// on long runs: a batch of such units took 300 ms instead of 24 when they were counted in).
 #define ZGPU_CLS_CHUNKS 32
 #define ZGPU_CLS_MIN_BYTES 4096u
 #define ZGPU_CLS_SAMPLES (64u * ZGPU_CLS_CHUNKS)
@@ -2464,10 +2494,13 @@ zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_fi
             const uint32_t b0 = b[c];
             const uint32_t nb = (uint32_t)__shfl_down((int)b0, 1);
             const uint32_t b1 = lane == 63u ? (uint32_t)last[c] : nb;
-            atomicAdd(&count[w][b0], 1u);
             const unsigned long long same = __ballot(b0 == b1);
-            one_value += same == ~0ull;
-            equal += (uint32_t)__builtin_popcountll(same);
+            if (same == ~0ull) {
+                ++one_value;
+            } else {  // (uniform) the statistics are those of the chunks that are not one value throughout
+                atomicAdd(&count[w][b0], 1u);
+                equal += (uint32_t)__builtin_popcountll(same);
+            }
         }
     }
     __syncthreads();
@@ -2479,8 +2512,9 @@ zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_fi
     for (int d = 32; d; d >>= 1) squares += __shfl_xor(squares, d);
     uint32_t values = 0;
     for (int i = 0; i < 4; ++i) values += (uint32_t)__builtin_popcountll(__ballot(count[w][i * 64 + lane] != 0u));
-    const bool few_values = squares * 200ull >= 31ull * ZGPU_CLS_SAMPLES * ZGPU_CLS_SAMPLES;  // 0.155
-    const bool short_runs = equal * 2u >= ZGPU_CLS_SAMPLES;
+    const uint32_t used = 64u * (ZGPU_CLS_CHUNKS - one_value);  // samples behind the statistics
+    const bool few_values = squares * 200ull >= 31ull * used * used;  // 0.155
+    const bool short_runs = equal * 2u >= used;
     if (live && lane == 0 && (few_values || short_runs) && one_value * 100u < 45u * ZGPU_CLS_CHUNKS) {
         // three lists (see the launches): at most six byte values; more values in short runs; more values, no runs
         const uint32_t which = values <= 6u ? 0u : short_runs ? 1u : 2u;
