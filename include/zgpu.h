@@ -150,36 +150,39 @@ int zgpu_set_search(int max_chain, int nice_length);
  * its deep_chain 0 speed with the default. */
 int zgpu_set_long_match(int deep_chain, int probe_fans);
 /* Dense input.  Where a few byte values carry a unit, or the unit is made of
- * short runs (two to six equally likely values, skewed alphabets, Markov
- * sources, words over ACGT or 01, 16-bit samples of small range, runs of up to
- * a hundred bytes) every 4-byte key has hundreds to thousands of earlier
- * occurrences and the longest of them is a few bytes longer than the longest
- * of the nearest max_chain -- at every position, which no bounded walk makes
- * up for (1.03-1.47 x the reference's size under FIXED, up to 1.29 x under
- * DYNAMIC at the default max_chain).  Every unit of at least 4 KiB is
- * therefore classified on the device before it is searched, from 32 samples of
- * 64 bytes: fewer than 45 % of the samples are one value throughout (runs of
- * hundreds of bytes need nothing more than the default search), and among the
- * other samples two bytes are equal with a chance of at least 0.155 (what six
- * equally likely values give; text: 0.05-0.08) or at least half of the bytes
- * equal their successor.  The units of that class are searched the reference's way
- * (src/rawdeflate.js:370-395: every candidate compared to its full length, the
- * longest wins, the nearest among equals), along at most max_chain candidates
- * per position (0..32768, default 2048; 0 = no such pass; units of more than
- * six byte values that are not made of short runs get an eighth of it, which
- * is as much as they need).  Their parse follows the content: units of at most
- * six byte values, and every such unit under DYNAMIC, defer a match only below
- * the caller's own `lazy` (0: the reference's greedy parse); the others, under
- * FIXED, keep the look-ahead of the default parse (see zgpu_set_min_lazy).
- * Such units then come out at
- * 0.99-1.02 x the reference's size in both modes (1024: up to 1.03 x, 4096: up
- * to 1.01 x, at half and twice the time) and take 3-55 ms per 64 KiB on their
- * compute unit instead of 0.4 -- 0.3-5 GB/s per GPU, where one CPU core runs
- * the reference's algorithm at 0.3-1.6 MB/s; other input pays the
- * classification and an empty launch, 0.2 % of its time.  The second search
- * starts when the first has finished: a batch with a few such units among
- * others ends later by the time of its slowest dense unit.  Not applied where
- * zgpu_set_search already asks for as much. */
+ * short runs (two to eight values, equally likely or skewed, Markov sources,
+ * words over ACGT or 01, 16-bit samples of small range, runs of up to a hundred
+ * bytes) every 4-byte key has hundreds to thousands of earlier occurrences and
+ * the longest of them is a few bytes longer than the longest of the nearest
+ * max_chain -- at every position, which no bounded walk makes up for
+ * (1.03-1.47 x the reference's size under FIXED, up to 1.29 x under DYNAMIC at
+ * the default max_chain).  Every unit of at least 4 KiB is therefore classified
+ * on the device before it is searched, from 32 samples of 64 bytes: fewer than
+ * 45 % of the samples are one value throughout (runs of hundreds of bytes need
+ * nothing more than the default search), and among the other samples two bytes
+ * are equal with a chance of at least 0.155 (what six equally likely values
+ * give; text: 0.05-0.08; 0.25 for a unit of more than eight values) or at
+ * least half of the bytes equal their successor.  The units of that class are
+ * searched a second time the reference's way (src/rawdeflate.js:370-395: every
+ * candidate compared to its full length, the longest wins, the nearest among
+ * equals), along at most max_chain candidates per position (0..32768, default
+ * 2048; 0 = no such pass).  Units of more than eight byte values -- zeros and
+ * small numbers in the tables of a binary: half of the units of a shared
+ * library qualify -- get a thirty-second of that: 64 candidates buy them 3 % of
+ * size under FIXED for half as much time again, where the whole budget buys
+ * 4.4 % for 18 x the time.  The parse follows the content: units of at most six
+ * byte values, and every unit of the class under DYNAMIC, defer a match only
+ * below the caller's own `lazy` (0: the reference's greedy parse); the others,
+ * under FIXED, keep the look-ahead of the default parse (see
+ * zgpu_set_min_lazy).  Units of few values then come out at 0.99-1.02 x the
+ * reference's size in both modes (1024: up to 1.03 x, 4096: up to 1.01 x, at
+ * half and twice the time) and take 3-55 ms per 64 KiB on their compute unit
+ * instead of 0.4 -- 0.3-5 GB/s per GPU, where one CPU core runs the reference's
+ * algorithm at 0.3-1.6 MB/s; units of the short search take 1-2 ms; other input
+ * pays the classification and three empty launches, 0.2 % of its time.  The
+ * second search starts when the first has finished: a batch with a few such
+ * units among others ends later by the time of its slowest dense unit.  Not
+ * applied where zgpu_set_search already asks for as much. */
 int zgpu_set_dense_search(int max_chain);
 /* In a batch of fewer than 16 units per compute unit, a unit longer than two
  * pieces is cut into pieces (batch bytes / 16 / compute units, at least

@@ -2458,10 +2458,14 @@ zgpu_emit_slots_kernel(EParams P) {
 //   * and fewer than 45 % of the chunks are one byte value throughout: runs of hundreds of bytes reach
 //     the maximum match length at the first candidates of their chains and need no second search (with
 //     run lengths up to 512 the share is 0.77 +- 0.07, up to 128 it is 0.25 +- 0.08).
+// How many distinct byte values the sample holds decides how much the unit gets: up to eight, it is the kind
+// of data the pass is for; with more -- zeros and small numbers in the tables of a binary, spaces in indented
+// text -- half of the units of a shared library qualify, and they get a short second search only.
 // The first two are taken over the chunks that are not one value throughout: a unit that is long runs in
 // part and text for the rest has few values by count, and is not dense (the second search is at its slowest
 // on long runs: a batch of such units took 300 ms instead of 24 when they were counted in).
 #define ZGPU_CLS_CHUNKS 32
+#define ZGPU_CLS_MAX_VALUES 8u
 #define ZGPU_CLS_MIN_BYTES 4096u
 #define ZGPU_CLS_SAMPLES (64u * ZGPU_CLS_CHUNKS)
 extern "C" __global__ void __launch_bounds__(256)
@@ -2513,11 +2517,14 @@ zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_fi
     uint32_t values = 0;
     for (int i = 0; i < 4; ++i) values += (uint32_t)__builtin_popcountll(__ballot(count[w][i * 64 + lane] != 0u));
     const uint32_t used = 64u * (ZGPU_CLS_CHUNKS - one_value);  // samples behind the statistics
-    const bool few_values = squares * 200ull >= 31ull * used * used;  // 0.155
+    // 0.155; a unit of more than eight values must reach 0.25 (indented source text has 0.15-0.17 for its
+    // spaces and gains nothing; the tables of a binary have 0.3-0.7 for their zeros)
+    const bool few_values = values <= ZGPU_CLS_MAX_VALUES ? squares * 200ull >= 31ull * used * used
+                                                          : squares * 4ull >= (unsigned long long)used * used;
     const bool short_runs = equal * 2u >= used;
     if (live && lane == 0 && (few_values || short_runs) && one_value * 100u < 45u * ZGPU_CLS_CHUNKS) {
-        // three lists (see the launches): at most six byte values; more values in short runs; more values, no runs
-        const uint32_t which = values <= 6u ? 0u : short_runs ? 1u : 2u;
+        // three lists (see the launches): at most six byte values; seven or eight in short runs; everything else
+        const uint32_t which = values <= 6u ? 0u : values <= ZGPU_CLS_MAX_VALUES && short_runs ? 1u : 2u;
         dense_list[which * list_stride + atomicAdd(dense_count + 2u * which, 1u)] = u;
     }
 }

@@ -1474,11 +1474,13 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
                 // where a literal has its fixed price (tables of small numbers among zeros: 1.05 x without,
                 // 1.03 x with); under DYNAMIC the code lengths follow the tokens and the reference's sizes come
                 // from its greedy parse of the same matches (16-bit tables in shared libraries: 1.03-1.05 x with
-                // the look-ahead, within the bar without).  (2) Of those, the units that are not made of short
-                // runs get an eighth of the chain budget: with more than six values in play and no runs a
-                // position's chain thins out quickly (skewed alphabets 1.00 x at 256 as at 2048; indented JSON
-                // that happens to fall into the class), and such a unit then costs 5 ms instead of 25; short
-                // runs of eight values need the whole budget (1.05 x at 256).
+                // the look-ahead, within the bar without).  (1) is short runs of seven or eight values, which
+                // need the whole chain budget (1.05 x at an eighth of it).  (2) is what else the statistics take:
+                // units of many byte values of which a few weigh heavily -- half of the units of a shared
+                // library, a tenth of indented source text.  The whole budget costs a batch of such units 18 x
+                // its time for 4.4 % of size under FIXED and 0.6 % under DYNAMIC; a thirty-second of it (64
+                // candidates, each compared to its full length) costs 1.5 x and buys 3.0 % and 0.3 %, which is
+                // what they get.
                 const int floor_lazy = p->lazy > p->knobs.min_lazy ? p->lazy : p->knobs.min_lazy;
                 for (uint32_t which = 0; which < 3; ++which) {
                     P.unit_list = p->b_dense.as<uint32_t>() + (size_t)which * p->dense_cap;
@@ -1486,7 +1488,7 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
                     P.unit_first = 0;
                     P.unit_end = 0xffffffffu;
                     P.counter = p->d_counter() + 6 * p->rounds.size() + 2 * which;
-                    P.max_chain = which == 2 ? (p->knobs.dense_chain + 7) / 8 : p->knobs.dense_chain;
+                    P.max_chain = which == 2 ? (p->knobs.dense_chain + 31) / 32 : p->knobs.dense_chain;
                     if (P.max_chain <= p->knobs.max_chain) P.max_chain = p->knobs.max_chain + 1;
                     P.nice = 258;
                     P.lazy = which && p->ctype == ZGPU_FIXED ? floor_lazy : p->lazy;
