@@ -393,6 +393,11 @@ napi_value DeflateBatch(napi_env env, napi_callback_info info) {
         // (1 GiB: 17 -> 25-30 GB/s through Node).
         bool one_step_done = false;
         if (own_out) {
+            // the streams are written while later inputs are still being read: the two must not share memory
+            if (src < own_out + own_cap && own_out < src + in_off[n]) {
+                napi_throw_type_error(env, nullptr, "output: the buffer overlaps the inputs");
+                return nullptr;
+            }
             rc = g.deflate_batch(src, in_off.data(), n, ctype, lazy, flags, own_out, own_cap, out_off.data(),
                                  want_crc ? crc.data() : nullptr, want_adler ? adler.data() : nullptr);
             if (rc) return throw_zgpu(env, "zgpu_deflate_batch", rc);

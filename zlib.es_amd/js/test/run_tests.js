@@ -329,6 +329,7 @@ it('allocInput: page-locked inputs and the one-step path give the bytes of ordin
 	}
 	assert.throws(() => Zlib.RawDeflate.compressBatch(cut(plain), { compressionType: CT.DYNAMIC, output: new Uint8Array(1000) }), /output/);
 	assert.throws(() => Zlib.RawDeflate.compressBatch(cut(plain), { compressionType: CT.DYNAMIC, output: [1, 2] }), TypeError);
+	assert.throws(() => Zlib.RawDeflate.compressBatch(cut(locked), { compressionType: CT.DYNAMIC, output: locked.subarray(1000) }), /overlaps/);
 	G.addon.hostTrim();
 });
 
