@@ -12,6 +12,8 @@ input resident in HBM.  Workloads (--workload):
   gzip      (config 5) 1 MiB chunks of one stream per GiB (each chunk primed with the 32 KiB
             before it, byte-aligned end), CRC-32 per chunk, combined on the host
   checksum  (config 2) CRC-32 + Adler-32 over one buffer
+  fewvalues (no BASELINE configuration) 64 KiB units of two to six equally likely byte values: what the
+            library's dense-class pass is for
 
 With --gpus N (launched through torch.distributed.run) every rank compresses
 its own batch of that size (weak scaling, no data-path collective); value =
@@ -151,7 +153,7 @@ def main():
     ap.add_argument("--unit-bytes", type=int, default=0, help="unit size (deflate), largest file (zip), chunk (gzip)")
     ap.add_argument("--ctype", type=int, default=2)
     ap.add_argument("--lazy", type=int, default=0)
-    ap.add_argument("--workload", default="deflate", choices=["deflate", "zip", "gzip", "checksum"])
+    ap.add_argument("--workload", default="deflate", choices=["deflate", "zip", "gzip", "checksum", "fewvalues"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-path and secondary-workload legs")
@@ -207,7 +209,10 @@ def main():
                     # the same 65536 x 64 KiB batch under FIXED coding (BASELINE config 3 names both modes)
                     "fixed": lambda: brief(bench_deflate(ctx, "deflate", short=True, ctype=1)),
                     # BASELINE config 2: CRC-32 + Adler-32 over 4 GiB
-                    "checksum": lambda: brief(bench_checksum(ctx, short=True))}
+                    "checksum": lambda: brief(bench_checksum(ctx, short=True)),
+                    # not a BASELINE configuration: small alphabets, which only the second, reference-like
+                    # search of the dense-class pass brings within 3 % of the reference's size
+                    "few_values": lambda: brief(bench_deflate(ctx, "fewvalues", short=True))}
             for name, leg in legs.items():
                 try:
                     res.setdefault("other_workloads", {})[name] = leg()
@@ -280,6 +285,18 @@ def make_workload(ctx, workload, short):
         return data, [(new_off[: nfx + 1].copy(), 1, N.F_FINAL_EACH | N.F_WANT_CRC, "FIXED files"),
                       (new_off[nfx:].copy(), 2, N.F_FINAL_EACH | N.F_WANT_CRC, "DYNAMIC files")], desc, {
                           "files_per_gpu": nf, "max_file_bytes": mx}
+    if workload == "fewvalues":
+        # units of two to six equally likely byte values: the content the bounded search cannot serve and the
+        # library's dense-class pass is for (every unit is classified on the device and searched a second time)
+        nu, ub = args.units or 512, args.unit_bytes or 65536
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed ^ 0xFE)
+        k = (torch.arange(nu, device=dev) % 5 + 2).unsqueeze(1)
+        data = ((torch.rand((nu, ub), device=dev, generator=g) * k).to(torch.uint8) * 37 + 1).to(torch.uint8).view(-1)
+        off = np.arange(nu + 1, dtype=np.uint64) * np.uint64(ub)
+        desc = ("batched RawDeflate, %d x %d B units of 2..6 equally likely byte values per GPU, compressionType %d, lazy %d"
+                % (nu, ub, args.ctype, args.lazy))
+        return data, [(off, args.ctype, N.F_FINAL_EACH, "units")], desc, {"units_per_gpu": nu, "unit_bytes": ub}
     if workload == "gzip":
         nc, cb = args.units or (1024 if short else 4096), args.unit_bytes or (1 << 20)
         data = gen_units(nc * (cb // 65536), 65536, seed, dev)
@@ -373,6 +390,9 @@ def bench_deflate(ctx, workload, short=False, ctype=None):
                            "traffic": traffic, "traffic_source": traffic_src,
                            "kernel": ("zgpu_deflate_quarter_kernel (units up to 8 KiB) / zgpu_deflate_half_kernel + "
                                       "zgpu_emit_small_kernel" if small_units else
+                                      "zgpu_deflate_kernel + zgpu_deflate_thorough_kernel (second search of the "
+                                      "classified units; inside search_kernel_ms) + zgpu_emit_kernel"
+                                      if workload == "fewvalues" else
                                       "zgpu_deflate_kernel + zgpu_emit_kernel"), "kernel_ms": round(k_ms, 3),
                            "search_kernel_ms": round(search_ms, 3), "emit_kernel_ms": round(emit_ms, 3),
                            "timing": "HIP events recorded by the library on the run's stream around the kernels of "
