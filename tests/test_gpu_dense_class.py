@@ -140,3 +140,23 @@ def test_dense_units_in_every_round_and_piece(z, monkeypatch):
     finally:
         z._native.set_dense_search()
     assert _sizes(z, [big], 1)[0] < 0.95 * plain
+
+
+def test_dense_small_files_among_others(z):
+    # files of 1-16 KiB take the small-window variants of the first search by size class; the dense ones among
+    # them (4 KiB and more) still get the second search, which runs in the full-window variant
+    rng = np.random.default_rng(8)
+    datas, dense = [], []
+    for i in range(300):
+        n = int(rng.integers(1, 16385))
+        if i % 7 == 3:
+            datas.append(zo.gen({"gen": "small-alpha", "n": n, "seed": 500 + i, "k": 2 + i % 4}))
+            if n >= 6000:
+                dense.append(i)
+        else:
+            datas.append(zo.gen({"gen": "text" if i % 2 else "rnd", "n": n, "seed": i}))
+    for ctype in (1, 2):
+        sizes = _sizes(z, datas, ctype)
+        bad = {i: sizes[i] / len(zo.rawdeflate(datas[i], ctype)) for i in dense
+               if sizes[i] > RATIO_BAR * len(zo.rawdeflate(datas[i], ctype))}
+        assert not bad, (ctype, bad)
