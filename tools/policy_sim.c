@@ -19,7 +19,8 @@
 #include "zo.h"
 
 #define HBITS 13
-#define MAXDIST (32768 - 64 * 48 - 128)
+#define MAXDIST (32768 - 64 * 54 - 128) /* the reach of the chain links; the kernel's one far candidate beyond it and its
+                                           three-byte stride scoring are not modelled */
 #define MAXN (1 << 21)
 
 typedef struct {
