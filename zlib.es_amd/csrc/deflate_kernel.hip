@@ -180,7 +180,7 @@ enum { M_SCAN = 0 /*[16]*/, M_UNIT = 32, M_NTOK = 34, M_TMP = 35, M_OVF = 36,
        M_LOCK = 45,    // try-lock of the parse frontier
        M_SAFE = 46,    // the frontier may pass items below this without looking at M_OLDEST
        M_LINKED = 47,  // all items below this have written their chain links
-       M_NEXT = 48,    // [9] the next unit: index, input offset (2), size, priming bytes, token offset (2), first block; tag
+       M_NEXT = 48,    // [10] the next unit: index, input offset (2), size, priming bytes, token offset (2), first block; tag; class
        M_OLDEST = 16   // [16] per wave: its oldest item whose tokens are not out yet (search kernel)
 };
 
@@ -633,6 +633,10 @@ struct Params {
     const uint32_t *unit_list;  // NULL: units unit_first .. unit_end; else list_len unit numbers (and unit_end = ~0)
     uint32_t list_len;
     const uint32_t *unit_prime; // per unit: bytes before it (same stream, multiple of 64, <= 32 KiB) that prime its window
+    const uint8_t *skip;        // NULL, or per unit: not zero = another launch searches this unit, pass it over
+    const uint8_t *unit_class;  // NULL, or per unit (thorough variant): class 1..3 of a unit picks its chain budget
+    int class_chain[3];         //   and its lazy value from these instead of max_chain and lazy
+    int class_lazy[3];
     unsigned long long *prof;   // 16 phase counters (diagnostic builds) or null
 };
 
@@ -683,8 +687,12 @@ __device__ __forceinline__ void search_units(const Params &P) {
     auto fetch_unit = [&](uint32_t tag) {
         // the queue hands out a range of units, or -- when a round's units are spread over kernel
         // variants by size -- the entries of a list
-        const uint32_t ticket = atomicAdd(P.counter, 1u);
-        const uint32_t nu = P.unit_list ? (ticket < P.list_len ? P.unit_list[ticket] : 0xffffffffu) : P.unit_first + ticket;
+        uint32_t nu;
+        for (;;) {
+            const uint32_t ticket = atomicAdd(P.counter, 1u);
+            nu = P.unit_list ? (ticket < P.list_len ? P.unit_list[ticket] : 0xffffffffu) : P.unit_first + ticket;
+            if (nu >= P.unit_end || !P.skip || !P.skip[nu]) break;
+        }
         uint64_t uo = 0, to = 0;
         uint32_t nn = 0, prm = 0, bf = 0;
         if (nu < P.unit_end) {
@@ -702,6 +710,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
         misc[M_NEXT + 5] = (uint32_t)to;
         misc[M_NEXT + 6] = (uint32_t)(to >> 32);
         misc[M_NEXT + 7] = bf;
+        if (THOROUGH) misc[M_NEXT + 9] = P.unit_class && nu < P.unit_end ? P.unit_class[nu] : 0u;
         asm volatile("" ::: "memory");
         lds_st(&misc[M_NEXT + 8], tag);  // the entries above are complete (LDS stores land in order)
     };
@@ -728,6 +737,10 @@ __device__ __forceinline__ void search_units(const Params &P) {
         const uint32_t prime_items = pr >> 6;
         uint16_t *tokbuf = P.tok + ((uint64_t)misc[M_NEXT + 5] | (uint64_t)misc[M_NEXT + 6] << 32);  // of the block in progress
         const uint32_t unit_blk_first = misc[M_NEXT + 7];
+        // chain budget and lazy value of this unit: the launch's, or (second search) those of the unit's class
+        const uint32_t ucls = THOROUGH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[M_NEXT + 9]) : 0u;
+        const int u_chain = !THOROUGH || !ucls ? P.max_chain : ucls == 1u ? P.class_chain[0] : ucls == 2u ? P.class_chain[1] : P.class_chain[2];
+        const int u_lazy = !THOROUGH || !ucls ? P.lazy : ucls == 1u ? P.class_lazy[0] : ucls == 2u ? P.class_lazy[1] : P.class_lazy[2];
         // Lower bounds of the parse frontier and of the ring's fill level that this wave has seen (both only
         // grow within a unit): an item whose bounds they already satisfy starts without reading the words --
         // two dependent LDS round trips fewer on the way to its linking turn.  Only in the variant with one
@@ -887,7 +900,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                 uint32_t adv = 1;
                 kind = 0;
                 if (best_len >= 3) {
-                    if (P.lazy > 0 && best_len < (uint32_t)P.lazy && l1 > best_len) {
+                    if (u_lazy > 0 && best_len < (uint32_t)u_lazy && l1 > best_len) {
                         kind = 2;
                         adv = 1 + l1;
                     } else {
@@ -1195,7 +1208,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     // down their chains is hardly ever used.  Three candidates then, instead of max_chain
                     // (incrementing-run units: sizes +0.1 %).  Only with the deep walk on: without it those positions
                     // are where the parse lands after a match that was cut short.
-                    int walk_budget = P.max_chain;
+                    int walk_budget = u_chain;
                     if (!THOROUGH && !whole && P.deep > 0 && P.max_chain > 3) {
                         const uint32_t cb = from_below(c, 0xfffffffeu);
                         if (__builtin_popcountll(__ballot(p + 4 <= n && ((c - cb) & 0xffffu) == 1u)) >= 48) walk_budget = 3;
@@ -2470,7 +2483,7 @@ zgpu_emit_slots_kernel(EParams P) {
 #define ZGPU_CLS_SAMPLES (64u * ZGPU_CLS_CHUNKS)
 extern "C" __global__ void __launch_bounds__(256)
 zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_first, uint32_t unit_end,
-                     uint32_t *dense_list, uint32_t list_stride, uint32_t *dense_count) {
+                     uint32_t *dense_list, uint32_t *dense_count, uint8_t *taken) {
     __shared__ uint32_t count[4][256];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const uint32_t u = unit_first + blockIdx.x * 4u + w;
@@ -2523,9 +2536,10 @@ zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_fi
                                                           : squares * 4ull >= (unsigned long long)used * used;
     const bool short_runs = equal * 2u >= used;
     if (live && lane == 0 && (few_values || short_runs) && one_value * 100u < 45u * ZGPU_CLS_CHUNKS) {
-        // three lists (see the launches): at most six byte values; seven or eight in short runs; everything else
+        // three classes (see the launch): at most six byte values; seven or eight in short runs; everything else
         const uint32_t which = values <= 6u ? 0u : values <= ZGPU_CLS_MAX_VALUES && short_runs ? 1u : 2u;
-        dense_list[which * list_stride + atomicAdd(dense_count + 2u * which, 1u)] = u;
+        dense_list[atomicAdd(dense_count, 1u)] = u;
+        taken[u] = (uint8_t)(1u + which);  // the first search passes the unit over; the second reads its class here
     }
 }
 

@@ -342,11 +342,17 @@ struct zgpu_plan {
     // listed at d_list + cls_at[c]; all zero: the round is of one class (by max_bytes) and runs as a range
     struct Round { uint32_t first, end; uint64_t max_bytes; uint32_t cls_at[3] = {0, 0, 0}, cls_len[3] = {0, 0, 0}; };
     uint32_t *d_list = nullptr;
-    // units of the dense content class, found on the device when the plan runs: b_dense holds three lists of
-    // the largest round's worth of unit numbers each (the tail 0xffffffff = no unit); their queue heads and
-    // counts are the six words of b_counter from 6 * rounds on
+    // units of the dense content class, found on the device when the plan runs: b_dense is a list of the
+    // largest round's worth of unit numbers (the tail 0xffffffff = no unit); its queue head and count are
+    // the two words of b_counter from 6 * rounds on
     DevBuf b_dense;
     uint32_t dense_cap = 0;  // 0: the plan has no such pass
+    // ... and one byte per unit (0, or 1 + its class) that says so to the first search, which passes those
+    // units over: the two searches run side by side, the first on a stream of the plan's own that forks from
+    // the caller's after the classification and joins it again before the emit kernel
+    DevBuf b_taken;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<Round> rounds;  // units whose tokens share the token buffer at one time
     std::vector<uint32_t> h_status;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -354,7 +360,7 @@ struct zgpu_plan {
     bool pooled = false;  // owned by a device's host context (not counted as a caller's live plan)
     void release_buffers() {
         for (DevBuf *b : {&d_tab, &b_out_off, &b_unit_out_off, &b_out_size, &b_status, &b_crc, &b_adler, &b_counter, &b_tok,
-                          &b_hist, &b_ntok, &b_state, &b_out_tmp, &b_seg_crc, &b_seg_adler, &b_dense})
+                          &b_hist, &b_ntok, &b_state, &b_out_tmp, &b_seg_crc, &b_seg_adler, &b_dense, &b_taken})
             b->release();
     }
 };
@@ -667,7 +673,7 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
     ENS(p->b_status, (size_t)n_pieces * 4);
     ENS(p->b_crc, (size_t)n_units * 4);
     ENS(p->b_adler, (size_t)n_units * 4);
-    ENS(p->b_counter, (p->rounds.size() * 6 + 6) * 4);
+    ENS(p->b_counter, (p->rounds.size() * 6 + 2) * 4);
     if (p->direct) ENS(p->b_state, (size_t)n_pieces * 8);
     if (ctype != ZGPU_NONE && !p->direct) ENS(p->b_out_tmp, acc + 64);
     if (ctype != ZGPU_NONE) {
@@ -680,7 +686,11 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
     if (ctype != ZGPU_NONE && p->knobs.dense_chain > p->knobs.max_chain && p->knobs.nice <= 32) {
         for (const auto &r : p->rounds)
             if (r.end - r.first > p->dense_cap) p->dense_cap = r.end - r.first;
-        ENS(p->b_dense, (size_t)p->dense_cap * 12);  // three lists
+        ENS(p->b_dense, (size_t)p->dense_cap * 4);
+        ENS(p->b_taken, (size_t)n_pieces);
+        if (!p->side) HIPCHK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+        if (!p->ev_fork) HIPCHK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+        if (!p->ev_join) HIPCHK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
     }
     if (p->split) ENS(p->b_unit_out_off, (size_t)(n_units + 1) * 8);
     if (p->n_segs) {
@@ -1377,6 +1387,9 @@ void zgpu_plan_destroy(zgpu_plan *p) {
     p->release_buffers();
     for (int i = 0; i < 5; ++i)
         if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+    if (p->side) (void)hipStreamDestroy(p->side);
     if (!p->pooled) --g_live;
     delete p;
 }
@@ -1388,7 +1401,7 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
     if ((uintptr_t)d_out & 3) return ZGPU_E_ARG;  // units that share a 32-bit word with a neighbour are stitched bytewise
     hipStream_t st = (hipStream_t)stream_;
     HIPCHK(hipEventRecord(p->ev[0], st));
-    HIPCHK(hipMemsetAsync(p->d_counter(), 0, (p->rounds.size() * 6 + 6) * 4, st));
+    HIPCHK(hipMemsetAsync(p->d_counter(), 0, (p->rounds.size() * 6 + 2) * 4, st));
     if (p->direct) HIPCHK(hipMemsetAsync(p->b_state.p, 0, (size_t)p->n_pieces * 8, st));
     HIPCHK(hipEventRecord(p->ev[1], st));
     if (p->ctype == ZGPU_NONE) {
@@ -1416,15 +1429,70 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             P.deep = p->knobs.deep;
             P.unit_prime = p->d_prime;
             P.prof = g_prof;
+            P.unit_class = nullptr;
+            for (int c = 0; c < 3; ++c) P.class_chain[c] = P.class_lazy[c] = 0;
             // one launch over the round's range, or one per size class over its list
             const auto &R = p->rounds[r];
             if (p->dense_cap) {
                 // which units are of the dense class (their list starts over with every round)
-                HIPCHK(hipMemsetAsync(p->b_dense.p, 0xff, (size_t)p->dense_cap * 12, st));
-                if (r) HIPCHK(hipMemsetAsync(p->d_counter() + 6 * p->rounds.size(), 0, 24, st));
+                HIPCHK(hipMemsetAsync(p->b_dense.p, 0xff, (size_t)p->dense_cap * 4, st));
+                if (r) HIPCHK(hipMemsetAsync(p->d_counter() + 6 * p->rounds.size(), 0, 8, st));
+                HIPCHK(hipMemsetAsync(p->b_taken.as<uint8_t>() + first, 0, cnt, st));
                 hipLaunchKernelGGL(zgpu_classify_kernel, dim3((cnt + 3) / 4), dim3(256), 0, st, (const uint8_t *)d_in,
-                                   p->d_in_off, first, end, p->b_dense.as<uint32_t>(), p->dense_cap,
-                                   p->d_counter() + 6 * p->rounds.size() + 1);
+                                   p->d_in_off, first, end, p->b_dense.as<uint32_t>(),
+                                   p->d_counter() + 6 * p->rounds.size() + 1, p->b_taken.as<uint8_t>());
+            }
+            P.skip = p->dense_cap ? p->b_taken.as<uint8_t>() : nullptr;
+            hipStream_t fs = st;  // the stream of the first search
+            if (p->dense_cap) {
+                // ... and those are searched as the reference searches (chain budget dense_chain, a match is good
+                // enough only at 258) by one launch of the thorough variant over that list, on the caller's
+                // stream, while the first search -- which passes them over (b_taken) -- runs on the plan's own
+                // stream.  The second search is enqueued first so that its workgroups -- one per unit in flight,
+                // each for milliseconds to tens of milliseconds -- are placed first, and the first search, whose
+                // workgroups draw units from a queue, fills the other CUs and those that become free: a few dense
+                // units then cost a batch nothing it can measure, where a second search after the first made
+                // every batch wait for its slowest dense unit (two units of 35 ms in 2 GiB of Python packages:
+                // 60 -> 107 ms one after the other, 60 -> 67 ms side by side).  The list ends at its first
+                // 0xffffffff entry: a workgroup that draws it is done, so with no dense unit in the round the
+                // launch takes a few microseconds.
+                // Three classes, one byte per unit (b_taken).  (1) Units of at most six byte values are parsed as
+                // the caller's lazy says (0: greedily, like the reference): a literal costs them eight or nine
+                // bits and a byte of a match a fraction of one, so putting a match off for a longer one loses
+                // (two values: 1.04 x the reference's size under FIXED with the look-ahead, 1.00 x without;
+                // 16-bit samples below six: 1.06 x against 1.00 x).  (2, 3) The others keep the look-ahead of the
+                // default parse under FIXED, where a literal has its fixed price (tables of small numbers among
+                // zeros: 1.05 x without, 1.03 x with); under DYNAMIC the code lengths follow the tokens and the
+                // reference's sizes come from its greedy parse of the same matches (16-bit tables in shared
+                // libraries: 1.03-1.05 x with the look-ahead, within the bar without).  (2) is short runs of
+                // seven or eight values, which need the whole chain budget (1.05 x at an eighth of it).  (3) is
+                // what else the statistics take: units of many byte values of which a few weigh heavily -- half
+                // of the units of a shared library, a tenth of indented source text.  The whole budget costs a
+                // batch of such units 18 x its time for 4.4 % of size under FIXED and 0.6 % under DYNAMIC; a
+                // thirty-second of it (64 candidates, each compared to its full length) costs 1.5 x and buys
+                // 3.0 % and 0.3 %, which is what they get.
+                const int floor_lazy = p->lazy > p->knobs.min_lazy ? p->lazy : p->knobs.min_lazy;
+                const int rest_lazy = p->ctype == ZGPU_FIXED ? floor_lazy : p->lazy;
+                int short_chain = (p->knobs.dense_chain + 31) / 32;
+                if (short_chain <= p->knobs.max_chain) short_chain = p->knobs.max_chain + 1;
+                HIPCHK(hipEventRecord(p->ev_fork, st));
+                HIPCHK(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+                fs = p->side;
+                Params D = P;
+                D.skip = nullptr;
+                D.unit_list = p->b_dense.as<uint32_t>();
+                D.list_len = cnt;
+                D.unit_first = 0;
+                D.unit_end = 0xffffffffu;
+                D.counter = p->d_counter() + 6 * p->rounds.size();
+                D.unit_class = p->b_taken.as<uint8_t>();
+                D.class_chain[0] = D.class_chain[1] = D.max_chain = p->knobs.dense_chain;
+                D.class_chain[2] = short_chain;
+                D.class_lazy[0] = D.lazy = p->lazy;
+                D.class_lazy[1] = D.class_lazy[2] = rest_lazy;
+                D.nice = 258;
+                const uint32_t cus = (uint32_t)p->ds->cus;
+                hipLaunchKernelGGL(zgpu_deflate_thorough_kernel, dim3(cnt < cus ? cnt : cus), dim3(1024), 0, st, D);
             }
             const bool has_lists = R.cls_len[0] + R.cls_len[1] + R.cls_len[2] != 0;
             const bool listed = has_lists && p->search_by_class;
@@ -1450,51 +1518,21 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
                 }
                 const uint32_t cus = (uint32_t)p->ds->cus;
                 if (p->knobs.nice > 32) {
-                    hipLaunchKernelGGL(zgpu_deflate_thorough_kernel, dim3(n_here < cus ? n_here : cus), dim3(1024), 0, st, P);
+                    hipLaunchKernelGGL(zgpu_deflate_thorough_kernel, dim3(n_here < cus ? n_here : cus), dim3(1024), 0, fs, P);
                 } else if (cls == 0) {
                     // tiny units: a unit's few items keep eight waves busy as well as sixteen, and four units
                     // per CU are in flight instead of two
-                    hipLaunchKernelGGL(zgpu_deflate_quarter_kernel, dim3(n_here < 4 * cus ? n_here : 4 * cus), dim3(512), 0, st, P);
+                    hipLaunchKernelGGL(zgpu_deflate_quarter_kernel, dim3(n_here < 4 * cus ? n_here : 4 * cus), dim3(512), 0, fs, P);
                 } else if (cls == 1) {
                     // units that fit half a window lose nothing to it: two workgroups per CU, 32 waves
-                    hipLaunchKernelGGL(zgpu_deflate_half_kernel, dim3(n_here < 2 * cus ? n_here : 2 * cus), dim3(1024), 0, st, P);
+                    hipLaunchKernelGGL(zgpu_deflate_half_kernel, dim3(n_here < 2 * cus ? n_here : 2 * cus), dim3(1024), 0, fs, P);
                 } else
-                    hipLaunchKernelGGL(zgpu_deflate_kernel, dim3(n_here < cus ? n_here : cus), dim3(1024), 0, st, P);
+                    hipLaunchKernelGGL(zgpu_deflate_kernel, dim3(n_here < cus ? n_here : cus), dim3(1024), 0, fs, P);
             }
+            // the second search of the classified units has run beside this one: the emit kernel needs both
             if (p->dense_cap) {
-                // ... and those are searched again as the reference searches (chain budget dense_chain, a match
-                // is good enough only at 258); the tokens, counts and histograms of the first search are
-                // overwritten.  A list ends at its first 0xffffffff entry: a workgroup that draws it is done,
-                // so with no dense unit in the round these launches take a few microseconds.
-                // Three lists.  (0) Units of at most six byte values are parsed as the caller's lazy says (0:
-                // greedily, like the reference): a literal costs them eight or nine bits and a byte of a match a
-                // fraction of one, so putting a match off for a longer one loses (two values: 1.04 x the
-                // reference's size under FIXED with the look-ahead, 1.00 x without; 16-bit samples below six:
-                // 1.06 x against 1.00 x).  (1, 2) The others keep the look-ahead of the default parse under FIXED,
-                // where a literal has its fixed price (tables of small numbers among zeros: 1.05 x without,
-                // 1.03 x with); under DYNAMIC the code lengths follow the tokens and the reference's sizes come
-                // from its greedy parse of the same matches (16-bit tables in shared libraries: 1.03-1.05 x with
-                // the look-ahead, within the bar without).  (1) is short runs of seven or eight values, which
-                // need the whole chain budget (1.05 x at an eighth of it).  (2) is what else the statistics take:
-                // units of many byte values of which a few weigh heavily -- half of the units of a shared
-                // library, a tenth of indented source text.  The whole budget costs a batch of such units 18 x
-                // its time for 4.4 % of size under FIXED and 0.6 % under DYNAMIC; a thirty-second of it (64
-                // candidates, each compared to its full length) costs 1.5 x and buys 3.0 % and 0.3 %, which is
-                // what they get.
-                const int floor_lazy = p->lazy > p->knobs.min_lazy ? p->lazy : p->knobs.min_lazy;
-                for (uint32_t which = 0; which < 3; ++which) {
-                    P.unit_list = p->b_dense.as<uint32_t>() + (size_t)which * p->dense_cap;
-                    P.list_len = cnt;
-                    P.unit_first = 0;
-                    P.unit_end = 0xffffffffu;
-                    P.counter = p->d_counter() + 6 * p->rounds.size() + 2 * which;
-                    P.max_chain = which == 2 ? (p->knobs.dense_chain + 31) / 32 : p->knobs.dense_chain;
-                    if (P.max_chain <= p->knobs.max_chain) P.max_chain = p->knobs.max_chain + 1;
-                    P.nice = 258;
-                    P.lazy = which && p->ctype == ZGPU_FIXED ? floor_lazy : p->lazy;
-                    const uint32_t cus = (uint32_t)p->ds->cus;
-                    hipLaunchKernelGGL(zgpu_deflate_thorough_kernel, dim3(cnt < cus ? cnt : cus), dim3(1024), 0, st, P);
-                }
+                HIPCHK(hipEventRecord(p->ev_join, fs));
+                HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
             }
             if (r == 0) HIPCHK(hipEventRecord(p->ev[4], st));
             EParams E;
