@@ -179,9 +179,12 @@ int zgpu_set_long_match(int deep_chain, int probe_fans);
  * half and twice the time) and take 3-55 ms per 64 KiB on their compute unit
  * instead of 0.4 -- 0.3-5 GB/s per GPU, where one CPU core runs the reference's
  * algorithm at 0.3-1.6 MB/s; units of the short search take 1-2 ms; other input
- * pays the classification and three empty launches, 0.2 % of its time.  The
- * second search starts when the first has finished: a batch with a few such
- * units among others ends later by the time of its slowest dense unit.  Not
+ * pays the classification and one empty launch, 0.2 % of its time.  The
+ * second search runs beside the first, which passes those units over (the
+ * first runs on a stream of the plan's own, forked from the caller's stream
+ * and joined to it again before the output is written): a batch with a few
+ * such units among others pays for their work, not for waiting on the slowest
+ * of them -- unless that one alone takes longer than everything else.  Not
  * applied where zgpu_set_search already asks for as much. */
 int zgpu_set_dense_search(int max_chain);
 /* In a batch of fewer than 16 units per compute unit, a unit longer than two

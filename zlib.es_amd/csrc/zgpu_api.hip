@@ -688,9 +688,14 @@ int plan_setup(zgpu_plan *p, const uint64_t *in_off, uint32_t n_units, int ctype
             if (r.end - r.first > p->dense_cap) p->dense_cap = r.end - r.first;
         ENS(p->b_dense, (size_t)p->dense_cap * 4);
         ENS(p->b_taken, (size_t)n_pieces);
-        if (!p->side) HIPCHK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-        if (!p->ev_fork) HIPCHK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-        if (!p->ev_join) HIPCHK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+        // (the plans of the host-buffer path keep both searches on their slot's stream: its sub-batches already
+        // overlap each other's kernels, and four more streams on the process's four hardware queues put a
+        // slot's copies behind another slot's kernels -- Node, 1 GiB page-locked in and out: 29 -> 40 ms)
+        if (!p->pooled) {
+            if (!p->side) HIPCHK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+            if (!p->ev_fork) HIPCHK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+            if (!p->ev_join) HIPCHK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+        }
     }
     if (p->split) ENS(p->b_unit_out_off, (size_t)(n_units + 1) * 8);
     if (p->n_segs) {
@@ -1444,6 +1449,7 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             }
             P.skip = p->dense_cap ? p->b_taken.as<uint8_t>() : nullptr;
             hipStream_t fs = st;  // the stream of the first search
+            Params D;
             if (p->dense_cap) {
                 // ... and those are searched as the reference searches (chain budget dense_chain, a match is good
                 // enough only at 258) by one launch of the thorough variant over that list, on the caller's
@@ -1475,10 +1481,12 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
                 const int rest_lazy = p->ctype == ZGPU_FIXED ? floor_lazy : p->lazy;
                 int short_chain = (p->knobs.dense_chain + 31) / 32;
                 if (short_chain <= p->knobs.max_chain) short_chain = p->knobs.max_chain + 1;
-                HIPCHK(hipEventRecord(p->ev_fork, st));
-                HIPCHK(hipStreamWaitEvent(p->side, p->ev_fork, 0));
-                fs = p->side;
-                Params D = P;
+                if (p->side) {
+                    HIPCHK(hipEventRecord(p->ev_fork, st));
+                    HIPCHK(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+                    fs = p->side;
+                }
+                D = P;
                 D.skip = nullptr;
                 D.unit_list = p->b_dense.as<uint32_t>();
                 D.list_len = cnt;
@@ -1491,8 +1499,7 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
                 D.class_lazy[0] = D.lazy = p->lazy;
                 D.class_lazy[1] = D.class_lazy[2] = rest_lazy;
                 D.nice = 258;
-                const uint32_t cus = (uint32_t)p->ds->cus;
-                hipLaunchKernelGGL(zgpu_deflate_thorough_kernel, dim3(cnt < cus ? cnt : cus), dim3(1024), 0, st, D);
+                if (p->side) hipLaunchKernelGGL(zgpu_deflate_thorough_kernel, dim3(cnt < (uint32_t)p->ds->cus ? cnt : (uint32_t)p->ds->cus), dim3(1024), 0, st, D);
             }
             const bool has_lists = R.cls_len[0] + R.cls_len[1] + R.cls_len[2] != 0;
             const bool listed = has_lists && p->search_by_class;
@@ -1530,7 +1537,13 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
                     hipLaunchKernelGGL(zgpu_deflate_kernel, dim3(n_here < cus ? n_here : cus), dim3(1024), 0, fs, P);
             }
             // the second search of the classified units has run beside this one: the emit kernel needs both
-            if (p->dense_cap) {
+            // (one stream: the second search follows the first.  In front of it, its workgroups -- a CU's worth of
+            // LDS each, though they have nothing to do -- would wait for the CUs that the sub-batch before this
+            // one still holds, and this sub-batch's first search behind them could no longer fill the CUs as
+            // they become free: Node, 1 GiB page-locked in and out, 29 -> 33 ms)
+            if (p->dense_cap && !p->side)
+                hipLaunchKernelGGL(zgpu_deflate_thorough_kernel, dim3(cnt < (uint32_t)p->ds->cus ? cnt : (uint32_t)p->ds->cus), dim3(1024), 0, st, D);
+            if (fs != st) {
                 HIPCHK(hipEventRecord(p->ev_join, fs));
                 HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
             }
