@@ -160,3 +160,51 @@ def test_dense_small_files_among_others(z):
         bad = {i: sizes[i] / len(zo.rawdeflate(datas[i], ctype)) for i in dense
                if sizes[i] > RATIO_BAR * len(zo.rawdeflate(datas[i], ctype))}
         assert not bad, (ctype, bad)
+
+
+@pytest.mark.parametrize("ctype", [1, 2])
+def test_device_resident_plan_on_a_callers_stream_gives_the_same_bytes(z, ctype, monkeypatch):
+    # zgpu_plan_run searches the dense units beside the others (the first search runs on a stream of the plan's own);
+    # the host-buffer call keeps both searches on one stream.  Same bytes either way, on a stream of the caller's,
+    # run after run (the lists and queue heads start over), with other work queued on that stream before and after,
+    # and with a token buffer that takes the batch in several rounds.
+    import torch
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(5)
+    datas = []
+    for i in range(48):
+        kind = i % 4
+        n = int(rng.integers(3000, 70000))
+        if kind == 0:
+            datas.append(zo.gen({"gen": "small-alpha", "n": n, "seed": 70 + i, "k": 2 + i % 7}))
+        elif kind == 1:
+            datas.append(zo.gen({"gen": "text", "n": n, "seed": i}))
+        elif kind == 2:
+            datas.append(np.repeat(rng.integers(0, 3, n // 4 + 1).astype(np.uint8) * 37, rng.integers(1, 9, n // 4 + 1))[:n])
+        else:
+            datas.append(zo.gen({"gen": "rnd", "n": n, "seed": i}))
+    datas = [np.ascontiguousarray(d) for d in datas]
+    want, _, _ = z.deflate_batch(datas, ctype, 0)
+    off = np.zeros(len(datas) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([d.size for d in datas])
+    flat = torch.from_numpy(np.concatenate(datas)).to(dev)
+    for tok_bytes in (None, 700000):
+        if tok_bytes:
+            monkeypatch.setenv("ZGPU_TOK_BYTES", str(tok_bytes))
+        plan = z.Plan(off, ctype, 0, 1)
+        out = torch.empty(plan.out_bound + 64, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.Stream()
+        noise = torch.empty(1 << 24, dtype=torch.float32, device=dev)
+        for rep in range(3):
+            with torch.cuda.stream(stream):
+                noise.normal_()  # the caller's own work in front of the call ...
+                plan.run(flat.data_ptr(), out.data_ptr(), out.numel(), stream.cuda_stream)
+                noise.mul_(2.0)  # ... and behind it
+                out_off, _, _ = plan.fetch(stream=stream.cuda_stream)
+            host = out.cpu().numpy()
+            for i, w in enumerate(want):
+                assert bytes(host[int(out_off[i]):int(out_off[i + 1])]) == bytes(w), (tok_bytes, rep, i)
+            out.zero_()
+        plan.close()
+        if tok_bytes:
+            monkeypatch.delenv("ZGPU_TOK_BYTES")
