@@ -2461,8 +2461,9 @@ zgpu_emit_slots_kernel(EParams P) {
 // In such data every 4-byte key has hundreds to thousands of earlier occurrences and the longest of them
 // is a few bytes longer than the longest of the nearest eight, at *every* position: the bounded walk of
 // the search kernel leaves 3-47 % of size against the reference's exhaustive one (src/rawdeflate.js:370-395),
-// where on other data it leaves nothing.  Units of that class are searched again by the thorough kernel
-// variant over the list written here (the second search replaces the tokens of the first).
+// where on other data it leaves nothing.  Units of that class are searched by the thorough kernel variant
+// over the list written here, with the settings of their class (the byte written to `taken`), and passed
+// over by the default search.
 // One wave per unit looks at ZGPU_CLS_CHUNKS chunks of 64 bytes spread evenly over the unit:
 //   * the chance that two of the sampled bytes are equal (sum of squared counts) is at least 0.155 --
 //     what six equally likely values give; seven give 0.143, text 0.05-0.08, which the default search

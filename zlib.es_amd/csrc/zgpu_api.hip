@@ -34,8 +34,9 @@ std::atomic<int> g_max_chain{8};
 std::atomic<int> g_nice{32};
 std::atomic<uint64_t> g_split_bytes{1ull << 20};  // units longer than twice this are cut into pieces of at most this size
 std::atomic<int> g_deep{96};       // long-match steps of the search kernel: deep-walk budget (0 = off)
-// units of the "dense" content class (zgpu_classify_kernel) are searched again with this chain budget,
-// nice_length 258 and the caller's own lazy value; 0 = no such pass
+// units of the "dense" content class (zgpu_classify_kernel) are searched with this chain budget (a
+// thirty-second of it for those of many byte values), nice_length 258 and a lazy value that follows the
+// class; 0 = no such pass
 std::atomic<int> g_dense_chain{2048};
 std::atomic<int> g_min_lazy{258};  // the parse always looks one position ahead unless told otherwise
 std::atomic<int> g_live{0};        // plans and jobs alive: zgpu_shutdown leaves the device state alone while any is
