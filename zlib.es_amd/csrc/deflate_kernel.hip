@@ -645,6 +645,26 @@ struct Params {
 // candidate is nice_length long or the chain budget ends -- with nice_length 258 and
 // a budget as long as the window that is the reference's exhaustive search
 // (src/rawdeflate.js:370-395: longest wins, the nearest among equals).
+// Thorough variant: runs of one byte value on a chain are scanned for their start instead of walked link by
+// link (see r_own in the walk), for positions that start at least ZGPU_RUN_MIN bytes of one value, in items
+// where at least ZGPU_RUN_LANES positions do; those items walk with the chain budget divided by
+// ZGPU_RUN_BUDGET_DIV.
+#ifndef ZGPU_RUN_MODE
+#define ZGPU_RUN_MODE 1
+#endif
+#ifndef ZGPU_RUN_MIN
+#define ZGPU_RUN_MIN 16u
+#endif
+#ifndef ZGPU_RUN_LANES
+#define ZGPU_RUN_LANES 32
+#endif
+#ifndef ZGPU_RUN_BUDGET_DIV
+#define ZGPU_RUN_BUDGET_DIV 4
+#endif
+template <bool V>
+struct RunTag {
+    static constexpr bool value = V;
+};
 template <bool THOROUGH, class C>
 __device__ __forceinline__ void search_units(const Params &P) {
     // the variant's geometry; these names shadow the full-window constants of the same name
@@ -1223,8 +1243,90 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         // matches).
                         const uint32_t cmpmax = maxlen < CMP_CAP ? maxlen : CMP_CAP;
                         uint32_t own_tail = 0;  // THOROUGH: this position's four bytes that end at offset blen
+                        // THOROUGH, a position that starts r_own bytes of one value (a run): its chain holds every
+                        // earlier position of every run of that value, hundreds to thousands of them, and what such a
+                        // candidate is worth follows from how much of its run lies in front of it (rc): rc < r_own
+                        // matches rc bytes, rc > r_own matches r_own, and only rc == r_own can go on past the run's
+                        // end.  So a run is not walked link by link: once rc is known for one candidate of it (two
+                        // dwords where the walk arrives at a run's end, or the compare it had to make anyway), the
+                        // bytes in front of the candidate are scanned sixteen at a time for the run's start (sx, rcx:
+                        // the scan's position and its rc); the candidate with rc == r_own, if the run has one, is
+                        // compared in full, the run's first position stands for all the shorter ones, and the walk
+                        // goes on from the link of the run's first position.  The same best match per run as the
+                        // link-by-link walk finds, in a sixteenth of the steps: such items get a quarter of the chain
+                        // budget and still reach four times as far (one 64 KiB unit of runs of up to 64 bytes of two
+                        // values: 46 -> 37 ms, 1.030 -> 1.009 x the reference's size under FIXED; up to 128 bytes of
+                        // four values: 37 -> 31 ms, 1.049 -> 1.003 x; with the whole budget 68 and 43 ms for 1.002 and
+                        // 1.006 x).
+                        uint32_t r_own = 0, sx = 0, rcx = 0;
+                        bool scan = false, run_item = false;
+                        if constexpr (THOROUGH && ZGPU_RUN_MODE) {
+                            if (p + 4 <= n && own.x == __builtin_amdgcn_alignbyte(own.x, own.x, 1u)) {
+                                uint32_t l = 0;  // how far the position matches itself one byte on
+                                for (;;) {
+                                    const uint32_t m = mlen16(ld16(ring, (pi + l) & (RING - 1)), ld16(ring, (pi + 1u + l) & (RING - 1)));
+                                    l += m;
+                                    if (m < 16u || l >= maxlen) break;
+                                }
+                                r_own = l + 1u < maxlen ? l + 1u : maxlen;
+                                if (r_own < ZGPU_RUN_MIN) r_own = 0;
+                            }
+                            // Only in items where half of the positions start sixteen bytes of a run or more: a wave runs
+                            // every path that one of its lanes takes, and these steps cost an item of a few short runs
+                            // (two values 90:10) three times its time for nothing.
+                            run_item = __builtin_popcountll(__ballot(r_own != 0u)) >= ZGPU_RUN_LANES;
+                            if (run_item) {
+                                walk_budget = walk_budget / ZGPU_RUN_BUDGET_DIV > 0 ? walk_budget / ZGPU_RUN_BUDGET_DIV : 1;
+                            } else {
+                                r_own = 0;
+                            }
+                        }
                         // one candidate of this lane's walk; false: the walk is over
-                        auto candidate = [&]() -> bool {
+                        auto candidate = [&](auto run_tag) -> bool {
+                            constexpr bool RUN = decltype(run_tag)::value;  // the item is mostly runs (see r_own)
+                            bool forced = false;
+                            if constexpr (RUN) {
+                                if (scan) {
+                                    // sixteen bytes in front of the scan's position: how many of them belong to the run
+                                    const uint32_t room = limit - ((p - sx) & 0xffffu);  // bytes in front of sx within the links' reach
+                                    const v4u v = ld16(ring, (sx - 16u) & (RING - 1));
+                                    const uint32_t x3 = v.w ^ own.x, x2 = v.z ^ own.x, x1 = v.y ^ own.x, x0 = v.x ^ own.x;
+                                    uint32_t t = x3 ? (uint32_t)__builtin_clz(x3) >> 3
+                                               : x2 ? 4u + ((uint32_t)__builtin_clz(x2) >> 3)
+                                               : x1 ? 8u + ((uint32_t)__builtin_clz(x1) >> 3)
+                                               : x0 ? 12u + ((uint32_t)__builtin_clz(x0) >> 3) : 16u;
+                                    const bool edge = t >= room;
+                                    t = edge ? room : t;
+                                    if (rcx < r_own && t >= r_own - rcx) {
+                                        // the run has a candidate with as much of it left as this position has: compared
+                                        // in full below, and the scan goes on from there for the run's start
+                                        c = (sx - (r_own - rcx)) & 0xffffu;
+                                        sx = c;
+                                        rcx = r_own;
+                                        forced = true;
+                                    } else if (t == 16u && !edge) {
+                                        sx = (sx - 16u) & 0xffffu;
+                                        rcx += 16u;
+                                        return true;
+                                    } else {
+                                        // the run's first position (or the last one within reach) stands for the shorter
+                                        // ones behind it; the walk goes on from its link
+                                        const uint32_t s0 = (sx - t) & 0xffffu, ls = rcx + t, ds = (p - s0) & 0xffffu;
+                                        const bool better = rcx < r_own && ls > blen;
+                                        blen = better ? ls : blen;
+                                        best_dist = better ? ds : best_dist;
+                                        own_tail = better ? own.x : own_tail;
+                                        scan = false;
+                                        if (edge || (better && ls >= (uint32_t)P.nice)) {
+                                            last = 0xffffu;
+                                            return false;
+                                        }
+                                        last = ds;
+                                        c = prevt[s0 & WMASK];
+                                        return true;
+                                    }
+                                }
+                            }
                             const uint32_t dist = (p - c) & 0xffffu;
                             if (dist <= last || dist > limit) {
                                 last = 0xffffu;
@@ -1233,6 +1335,27 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             last = dist;
                             const uint32_t ci = c & (RING - 1);
                             const uint32_t nxt = prevt[c & WMASK];
+                            const uint32_t c_cur = c;
+                            if constexpr (RUN) {
+                                if (r_own && !forced) {
+                                    // the end of an earlier run: four bytes of the value, then another
+                                    const uint32_t *w = (const uint32_t *)(ring + (ci & ~3u));
+                                    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+                                    const uint32_t first4 = __builtin_amdgcn_alignbyte(w1, w0, ci & 3u);
+                                    const uint32_t fifth = __builtin_amdgcn_alignbyte(w2, w1, ci & 3u) & 0xffu;
+                                    if (first4 == own.x && fifth != (own.x & 0xffu)) {
+                                        const bool better = 4u > blen;
+                                        blen = better ? 4u : blen;
+                                        best_dist = better ? dist : best_dist;
+                                        own_tail = better ? own.x : own_tail;
+                                        scan = true;
+                                        sx = c_cur;
+                                        rcx = 4u;
+                                        c = nxt;
+                                        return !(better && 4u >= (uint32_t)P.nice);
+                                    }
+                                }
+                            }
                             if (THOROUGH) {
                                 // Only a longer match replaces the best so far (the walk goes from near to far and
                                 // the nearest of equals wins), and a longer one agrees with this position in the
@@ -1268,6 +1391,21 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             } else if (len > cmpmax) {
                                 len = cmpmax;
                             }
+                            if constexpr (RUN) {
+                                if (r_own && !forced) {
+                                    // what the compare says about the candidate's run: it ends after len bytes, or
+                                    // (the match ends with this position's run and the candidate's goes on) later
+                                    if (len >= 4u && len < r_own) {
+                                        scan = true;
+                                        sx = c_cur;
+                                        rcx = len;
+                                    } else if (len == r_own && r_own < maxlen && ring[(ci + r_own) & (RING - 1)] == (own.x & 0xffu)) {
+                                        scan = true;
+                                        sx = c_cur;
+                                        rcx = r_own + 1u;
+                                    }
+                                }
+                            }
                             c = nxt;
                             // selects, not a branch: every branch the wave can diverge on costs a
                             // handful of scalar instructions per candidate, and the scalar unit is
@@ -1292,14 +1430,21 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         };
                         if (p + 4 <= n) {
                             last = 0;
-                            for (int budget = walk_budget; budget > 0; --budget) {
-                                // two candidates in and not one position of the item (of those still walking) has
-                                // found four bytes that repeat: incompressible data, whose chains hold hash
-                                // collisions only -- the walk ends for the whole item (random units 56.6 -> 66.6
-                                // GB/s; no named input and none of the bench's kinds changes size; ending after
-                                // one candidate is no faster)
-                                if (!THOROUGH && budget == walk_budget - 2 && !__ballot(blen >= 4u)) break;
-                                if (!candidate()) break;
+                            if (THOROUGH && ZGPU_RUN_MODE && run_item) {
+                                // (a loop of its own: with the run steps in the one loop, items without runs took
+                                // half as long again for code they never reach)
+                                for (int budget = walk_budget; budget > 0; --budget)
+                                    if (!candidate(RunTag<THOROUGH && ZGPU_RUN_MODE>{})) break;
+                            } else {
+                                for (int budget = walk_budget; budget > 0; --budget) {
+                                    // two candidates in and not one position of the item (of those still walking) has
+                                    // found four bytes that repeat: incompressible data, whose chains hold hash
+                                    // collisions only -- the walk ends for the whole item (random units 56.6 -> 66.6
+                                    // GB/s; no named input and none of the bench's kinds changes size; ending after
+                                    // one candidate is no faster)
+                                    if (!THOROUGH && budget == walk_budget - 2 && !__ballot(blen >= 4u)) break;
+                                    if (!candidate(RunTag<false>{})) break;
+                                }
                             }
                             if constexpr (C::FULL_DISTANCE && ZGPU_FAR_BLOCK) {
                                 // A walk that ran out of the links' reach stands at a candidate that is still worth a
@@ -2481,6 +2626,9 @@ zgpu_emit_slots_kernel(EParams P) {
 #define ZGPU_CLS_CHUNKS 32
 #define ZGPU_CLS_MAX_VALUES 8u
 #define ZGPU_CLS_MIN_BYTES 4096u
+#ifndef ZGPU_CLS_ONE_VALUE_PCT
+#define ZGPU_CLS_ONE_VALUE_PCT 45u
+#endif
 #define ZGPU_CLS_SAMPLES (64u * ZGPU_CLS_CHUNKS)
 extern "C" __global__ void __launch_bounds__(256)
 zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_first, uint32_t unit_end,
@@ -2536,7 +2684,7 @@ zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_fi
     const bool few_values = values <= ZGPU_CLS_MAX_VALUES ? squares * 200ull >= 31ull * used * used
                                                           : squares * 4ull >= (unsigned long long)used * used;
     const bool short_runs = equal * 2u >= used;
-    if (live && lane == 0 && (few_values || short_runs) && one_value * 100u < 45u * ZGPU_CLS_CHUNKS) {
+    if (live && lane == 0 && (few_values || short_runs) && one_value * 100u < ZGPU_CLS_ONE_VALUE_PCT * ZGPU_CLS_CHUNKS) {
         // three classes (see the launch): at most six byte values; seven or eight in short runs; everything else
         const uint32_t which = values <= 6u ? 0u : values <= ZGPU_CLS_MAX_VALUES && short_runs ? 1u : 2u;
         dense_list[atomicAdd(dense_count, 1u)] = u;
