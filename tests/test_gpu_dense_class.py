@@ -213,3 +213,34 @@ def test_device_resident_plan_on_a_callers_stream_gives_the_same_bytes(z, ctype,
         plan.close()
         if tok_bytes:
             monkeypatch.delenv("ZGPU_TOK_BYTES")
+
+
+def test_runs_in_long_units_and_primed_pieces(z):
+    # the run scan of the thorough walk where positions wrap around the 64 KiB ring, where a piece's window starts
+    # in the bytes before it, at the very start of a unit (nothing in front of the first run) and with runs that
+    # reach the unit's end; the dense-class pass and the thorough search for everything
+    rng = np.random.default_rng(77)
+
+    def runs(n, k, maxlen, lead=0):
+        lens = rng.integers(1, maxlen + 1, n // 2 + 2)
+        vals = (rng.integers(0, k, lens.size) * 37 + 1).astype(np.uint8)
+        d = np.repeat(vals, lens)[:n].copy()
+        if lead:
+            d[:lead] = d[0]
+        return np.ascontiguousarray(d)
+
+    datas = [runs(200000, 2, 64), runs(150001, 4, 128, lead=300), runs(70000, 3, 40), runs(65536 * 3 + 17, 2, 100),
+             runs(9000, 2, 64), np.concatenate([runs(100000, 4, 64), np.full(5000, 38, dtype=np.uint8)]),
+             runs(3 << 20, 4, 90)]
+    for ctype in (1, 2):
+        sizes = _sizes(z, datas, ctype)  # (round trip checked inside)
+        for d, s in zip(datas[:6], sizes):
+            assert s <= RATIO_BAR * len(zo.rawdeflate(d, ctype)), (ctype, d.size)
+    z._native.set_search(32768, 258)
+    try:
+        for ctype in (1, 2):
+            sizes = _sizes(z, datas[:6], ctype)
+            for d, s in zip(datas[:6], sizes):
+                assert s <= RATIO_BAR * len(zo.rawdeflate(d, ctype)), (ctype, d.size)
+    finally:
+        z._native.set_search()
