@@ -287,7 +287,12 @@ uint64_t zgpu_plan_out_bound(const zgpu_plan *plan);
  * write every unit straight to its final place (sizes first, then offsets by
  * a look-back among the units in flight); plans with a round of smaller units
  * stage them in a workspace and gather.  stream: hipStream_t (NULL = default
- * stream).  Returns after enqueueing. */
+ * stream).  Returns after enqueueing.  With the dense-class pass on (see
+ * zgpu_set_dense_search) part of the work runs on a stream that the plan
+ * owns, forked from `stream` by an event after the call's first kernels and
+ * joined to it by another before its last: whatever the caller enqueues on
+ * `stream` after the call is ordered after all of it, as if the plan used
+ * `stream` alone.  One run of a plan at a time (its workspace is one). */
 int zgpu_plan_run(zgpu_plan *plan, const void *d_in, void *d_out, uint64_t out_cap, void *stream);
 /* Device-side results of the last run (valid once the stream has drained):
  * out_off: n_units+1 x uint64, crc/adler: n_units x uint32 (zero unless
