@@ -653,7 +653,7 @@ struct Params {
 #define ZGPU_RUN_MODE 1
 #endif
 #ifndef ZGPU_RUN_MIN
-#define ZGPU_RUN_MIN 16u
+#define ZGPU_RUN_MIN 16u  // more than the twelve bytes that tell a run's end
 #endif
 #ifndef ZGPU_RUN_LANES
 #define ZGPU_RUN_LANES 32
@@ -758,7 +758,11 @@ __device__ __forceinline__ void search_units(const Params &P) {
         uint16_t *tokbuf = P.tok + ((uint64_t)misc[M_NEXT + 5] | (uint64_t)misc[M_NEXT + 6] << 32);  // of the block in progress
         const uint32_t unit_blk_first = misc[M_NEXT + 7];
         // chain budget and lazy value of this unit: the launch's, or (second search) those of the unit's class
-        const uint32_t ucls = THOROUGH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[M_NEXT + 9]) : 0u;
+        const uint32_t ubyte = THOROUGH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[M_NEXT + 9]) : 0u;
+        const uint32_t ucls = ubyte & 3u;
+        // bytes five to eight of a position that go into its chain key besides the first four (none, one, two, four)
+        const uint32_t ukey = ubyte >> 4;
+        const uint32_t key_mask = ukey == 0u ? 0u : ukey == 1u ? 0xffu : ukey == 2u ? 0xffffu : 0xffffffffu;
         const int u_chain = !THOROUGH || !ucls ? P.max_chain : ucls == 1u ? P.class_chain[0] : ucls == 2u ? P.class_chain[1] : P.class_chain[2];
         const int u_lazy = !THOROUGH || !ucls ? P.lazy : ucls == 1u ? P.class_lazy[0] : ucls == 2u ? P.class_lazy[1] : P.class_lazy[2];
         // Lower bounds of the parse frontier and of the ring's fill level that this wave has seen (both only
@@ -1097,7 +1101,20 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     uint32_t key = 0xffffffffu;
                     {
                         const uint32_t *w = (const uint32_t *)(ring + (ip & (RING - 1) & ~3u));
-                        const uint32_t first4 = __builtin_amdgcn_alignbyte(w[1], w[0], ip & 3u);
+                        uint32_t first4 = __builtin_amdgcn_alignbyte(w[1], w[0], ip & 3u);
+                        if constexpr (THOROUGH) {
+                            // Units of a very few byte values (the dense class says how few): a chain keyed on four
+                            // bytes holds a sixteenth of a two-valued unit's positions, and every one of them is a
+                            // candidate the walk must at least test; keyed on eight, a 256th, and the matches that
+                            // such data has are longer than eight bytes anyway.  The bytes past the unit's end are
+                            // not part of a key.
+                            if (key_mask && ip + 4 <= n) {
+                                const uint32_t left = n - ip - 4u;
+                                uint32_t next4 = __builtin_amdgcn_alignbyte(w[2], w[1], ip & 3u) & key_mask;
+                                if (left < 4u) next4 &= (1u << (left << 3)) - 1u;
+                                first4 ^= next4 * 0x2545F491u;
+                            }
+                        }
                         if (ip + 4 <= n) key = (hash4<HBITS>(first4) << 6) | (uint32_t)lane;  // all four bytes inside the unit
                     }
                     key = wave_sort64(key);
@@ -1338,21 +1355,26 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             const uint32_t c_cur = c;
                             if constexpr (RUN) {
                                 if (r_own && !forced) {
-                                    // the end of an earlier run: four bytes of the value, then another
+                                    // the end of an earlier run: as many bytes of the value as the chains are keyed on
+                                    // (four to eight), then another -- told from the candidate's first twelve bytes
                                     const uint32_t *w = (const uint32_t *)(ring + (ci & ~3u));
-                                    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-                                    const uint32_t first4 = __builtin_amdgcn_alignbyte(w1, w0, ci & 3u);
-                                    const uint32_t fifth = __builtin_amdgcn_alignbyte(w2, w1, ci & 3u) & 0xffu;
-                                    if (first4 == own.x && fifth != (own.x & 0xffu)) {
-                                        const bool better = 4u > blen;
-                                        blen = better ? 4u : blen;
+                                    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+                                    const uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, ci & 3u) ^ own.x;
+                                    const uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, ci & 3u) ^ own.x;
+                                    const uint32_t x2 = __builtin_amdgcn_alignbyte(w3, w2, ci & 3u) ^ own.x;
+                                    const uint32_t lead = x0 ? (uint32_t)__builtin_ctz(x0) >> 3
+                                                        : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3)
+                                                        : x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3) : 12u;
+                                    if (lead >= 4u && lead < 12u) {  // (r_own is 16 at least)
+                                        const bool better = lead > blen;
+                                        blen = better ? lead : blen;
                                         best_dist = better ? dist : best_dist;
                                         own_tail = better ? own.x : own_tail;
                                         scan = true;
                                         sx = c_cur;
-                                        rcx = 4u;
+                                        rcx = lead;
                                         c = nxt;
-                                        return !(better && 4u >= (uint32_t)P.nice);
+                                        return !(better && lead >= (uint32_t)P.nice);
                                     }
                                 }
                             }
@@ -2626,6 +2648,9 @@ zgpu_emit_slots_kernel(EParams P) {
 #define ZGPU_CLS_CHUNKS 32
 #define ZGPU_CLS_MAX_VALUES 8u
 #define ZGPU_CLS_MIN_BYTES 4096u
+#ifndef ZGPU_DENSE_LONG_KEY
+#define ZGPU_DENSE_LONG_KEY 1
+#endif
 #ifndef ZGPU_CLS_ONE_VALUE_PCT
 #define ZGPU_CLS_ONE_VALUE_PCT 45u
 #endif
@@ -2688,7 +2713,18 @@ zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_fi
         // three classes (see the launch): at most six byte values; seven or eight in short runs; everything else
         const uint32_t which = values <= 6u ? 0u : values <= ZGPU_CLS_MAX_VALUES && short_runs ? 1u : 2u;
         dense_list[atomicAdd(dense_count, 1u)] = u;
-        taken[u] = (uint8_t)(1u + which);  // the first search passes the unit over; the second reads its class here
+        // Units of at most six values: how many bytes key their chains.  With q the chance that two bytes are equal, a
+        // key of L bytes leaves n * q^L candidates per chain on average; the longest key that still leaves 32 of them
+        // (so that a match of at least that length is there to be found), from four bytes up to eight.
+        uint32_t key_code = 0;
+        if (which == 0u && ZGPU_DENSE_LONG_KEY) {
+            const float q = (float)squares / ((float)used * (float)used);
+            const float window = un < 32768ull ? (float)un : 32768.0f;
+            const float len = __logf(window * (1.0f / 32.0f)) / -__logf(q < 0.999f ? q : 0.999f);
+            key_code = len >= 8.0f ? 3u : len >= 6.0f ? 2u : len >= 5.0f ? 1u : 0u;
+        }
+        // the first search passes the unit over; the second reads its class (and key length) here
+        taken[u] = (uint8_t)(1u + which + (key_code << 4));
     }
 }
 
