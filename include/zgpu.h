@@ -176,12 +176,12 @@ int zgpu_set_long_match(int deep_chain, int probe_fans);
  * under FIXED, keep the look-ahead of the default parse (see
  * zgpu_set_min_lazy).  Units of few values then come out at 0.99-1.02 x the
  * reference's size in both modes (1024: up to 1.03 x, 4096: up to 1.01 x, at
- * half and twice the time) and take 1-50 ms per 64 KiB on their compute unit
+ * half and twice the time) and take 1-35 ms per 64 KiB on their compute unit
  * instead of 0.4 -- equally likely values 1-5 ms (their hash chains are keyed
- * on up to eight bytes instead of four), skewed two- and three-valued data and
- * short runs 30-50 ms: 0.3-15 GB/s per GPU, where one CPU core runs the
- * reference's algorithm at 0.3-1.6 MB/s; units of the short search take
- * 1-2 ms; other input
+ * on up to eight bytes instead of four), runs 4-20 ms (their positions are
+ * keyed on value and run length), skewed two- and three-valued data 17-35 ms:
+ * 0.5-15 GB/s per GPU, where one CPU core runs the reference's algorithm at
+ * 0.3-1.6 MB/s; units of the short search take 1-2 ms; other input
  * pays the classification and one empty launch, 0.2 % of its time.  The
  * second search runs beside the first, which passes those units over (the
  * first runs on a stream of the plan's own, forked from the caller's stream

@@ -79,9 +79,9 @@ def _families():
         "runs <= 8 of 3": runs_of(3, 8),
         "runs <= 16 of 8": runs_of(8, 16),
         "runs <= 32 of 4": runs_of(4, 32),
-        # (runs on a chain are scanned for their start, not walked link by link: up to 64 bytes of two values was
-        # 1.02-1.035 x depending on the seed, up to 128 of four 1.05 x.  Up to 128 of two values -- which are runs of
-        # up to several hundred, as equal neighbours merge -- is past the class's limit on one-value samples: 1.08 x)
+        # (the positions of a run are keyed on its value and length: up to 64 bytes of two values was 1.02-1.035 x
+        # depending on the seed, up to 128 of four 1.05 x.  Up to 128 of two values -- which are runs of up to several
+        # hundred, as equal neighbours merge -- is past the class's limit on one-value samples: 1.08 x)
         "runs <= 64 of 2": runs_of(2, 64),
         "runs <= 128 of 4": runs_of(4, 128),
         "16-bit samples below 6": np.stack([rng.integers(0, 6, n // 2).astype(np.uint8), np.zeros(n // 2, dtype=np.uint8)], 1).reshape(-1),
@@ -216,9 +216,9 @@ def test_device_resident_plan_on_a_callers_stream_gives_the_same_bytes(z, ctype,
 
 
 def test_runs_in_long_units_and_primed_pieces(z):
-    # the run scan of the thorough walk where positions wrap around the 64 KiB ring, where a piece's window starts
-    # in the bytes before it, at the very start of a unit (nothing in front of the first run) and with runs that
-    # reach the unit's end; the dense-class pass and the thorough search for everything
+    # the run keys of the thorough variant where positions wrap around the 64 KiB ring, where a piece's window
+    # starts in the bytes before it, at the very start of a unit (nothing in front of the first run) and with runs
+    # that reach the unit's end; the dense-class pass and the thorough search for everything
     rng = np.random.default_rng(77)
 
     def runs(n, k, maxlen, lead=0):

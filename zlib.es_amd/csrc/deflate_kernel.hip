@@ -645,26 +645,11 @@ struct Params {
 // candidate is nice_length long or the chain budget ends -- with nice_length 258 and
 // a budget as long as the window that is the reference's exhaustive search
 // (src/rawdeflate.js:370-395: longest wins, the nearest among equals).
-// Thorough variant: runs of one byte value on a chain are scanned for their start instead of walked link by
-// link (see r_own in the walk), for positions that start at least ZGPU_RUN_MIN bytes of one value, in items
-// where at least ZGPU_RUN_LANES positions do; those items walk with the chain budget divided by
-// ZGPU_RUN_BUDGET_DIV.
-#ifndef ZGPU_RUN_MODE
-#define ZGPU_RUN_MODE 1
+// Thorough variant: positions that start eight or more bytes of one value are keyed on the value and the number
+// of those bytes (see the insert step).
+#ifndef ZGPU_RUN_KEY
+#define ZGPU_RUN_KEY 1
 #endif
-#ifndef ZGPU_RUN_MIN
-#define ZGPU_RUN_MIN 16u  // more than the twelve bytes that tell a run's end
-#endif
-#ifndef ZGPU_RUN_LANES
-#define ZGPU_RUN_LANES 32
-#endif
-#ifndef ZGPU_RUN_BUDGET_DIV
-#define ZGPU_RUN_BUDGET_DIV 4
-#endif
-template <bool V>
-struct RunTag {
-    static constexpr bool value = V;
-};
 template <bool THOROUGH, class C>
 __device__ __forceinline__ void search_units(const Params &P) {
     // the variant's geometry; these names shadow the full-window constants of the same name
@@ -1102,13 +1087,45 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     {
                         const uint32_t *w = (const uint32_t *)(ring + (ip & (RING - 1) & ~3u));
                         uint32_t first4 = __builtin_amdgcn_alignbyte(w[1], w[0], ip & 3u);
+                        bool run_key = false;
+                        if constexpr (THOROUGH && ZGPU_RUN_KEY) {
+                            // A position that starts eight or more bytes of one value is keyed on the value and on how
+                            // many bytes of it there are (up to 258).  Keyed on its first bytes it shares a chain with
+                            // every position of every run of the value, hundreds to thousands of them; of a run's
+                            // positions, though, only the one with as much of the run in front of it can match past the
+                            // run's end -- those nearer the end match less, those further from it as much as this
+                            // position has of its run, which the position one byte back (scored for the whole item
+                            // before the walks) gives as well.  Keyed this way the chain holds that one position of
+                            // every earlier run that is long enough, and nothing else.
+                            const uint32_t b = first4 & 0xffu;
+                            const unsigned long long eq = __ballot(ip + 1u < n && ring[(ip + 1u) & (RING - 1)] == b);
+                            const unsigned long long rest = ~(eq >> lane);  // zeros shifted in from the top end the count
+                            const uint32_t ones = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+                            uint32_t r = ones + 1u;
+                            if (eq >> 63) {
+                                // the item's last byte goes on into the next ones: how far, for the lanes it reaches
+                                uint32_t ext = 0;
+                                for (uint32_t q = 0; q < 4u; ++q) {
+                                    const uint32_t jx = ip0 + 64u + (q << 6) + (uint32_t)lane;
+                                    const unsigned long long off = ~__ballot(jx < n && ring[jx & (RING - 1)] == rl(b, 63));
+                                    ext += off ? (uint32_t)__builtin_ctzll(off) : 64u;
+                                    if (off) break;
+                                }
+                                if (ones == 64u - (uint32_t)lane) r = ones + ext;
+                            }
+                            r = r < 258u ? r : 258u;
+                            if (r >= 8u && ip + 4u <= n) {
+                                first4 = ((r << 8 | b) * 0x85EBCA6Bu) ^ 0x5bd1e995u;
+                                run_key = true;
+                            }
+                        }
                         if constexpr (THOROUGH) {
                             // Units of a very few byte values (the dense class says how few): a chain keyed on four
                             // bytes holds a sixteenth of a two-valued unit's positions, and every one of them is a
                             // candidate the walk must at least test; keyed on eight, a 256th, and the matches that
                             // such data has are longer than eight bytes anyway.  The bytes past the unit's end are
                             // not part of a key.
-                            if (key_mask && ip + 4 <= n) {
+                            if (key_mask && !run_key && ip + 4 <= n) {
                                 const uint32_t left = n - ip - 4u;
                                 uint32_t next4 = __builtin_amdgcn_alignbyte(w[2], w[1], ip & 3u) & key_mask;
                                 if (left < 4u) next4 &= (1u << (left << 3)) - 1u;
@@ -1246,6 +1263,10 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     // (incrementing-run units: sizes +0.1 %).  Only with the deep walk on: without it those positions
                     // are where the parse lands after a match that was cut short.
                     int walk_budget = u_chain;
+                    if constexpr (THOROUGH && ZGPU_RUN_KEY) {
+                        // (see the chain keys of positions inside runs) the match one byte back, for the whole item
+                        if (__ballot(p + 4 <= n && own.x == __builtin_amdgcn_alignbyte(own.x, own.x, 1u))) score_distance(1u);
+                    }
                     if (!THOROUGH && !whole && P.deep > 0 && P.max_chain > 3) {
                         const uint32_t cb = from_below(c, 0xfffffffeu);
                         if (__builtin_popcountll(__ballot(p + 4 <= n && ((c - cb) & 0xffffu) == 1u)) >= 48) walk_budget = 3;
@@ -1260,90 +1281,15 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         // matches).
                         const uint32_t cmpmax = maxlen < CMP_CAP ? maxlen : CMP_CAP;
                         uint32_t own_tail = 0;  // THOROUGH: this position's four bytes that end at offset blen
-                        // THOROUGH, a position that starts r_own bytes of one value (a run): its chain holds every
-                        // earlier position of every run of that value, hundreds to thousands of them, and what such a
-                        // candidate is worth follows from how much of its run lies in front of it (rc): rc < r_own
-                        // matches rc bytes, rc > r_own matches r_own, and only rc == r_own can go on past the run's
-                        // end.  So a run is not walked link by link: once rc is known for one candidate of it (two
-                        // dwords where the walk arrives at a run's end, or the compare it had to make anyway), the
-                        // bytes in front of the candidate are scanned sixteen at a time for the run's start (sx, rcx:
-                        // the scan's position and its rc); the candidate with rc == r_own, if the run has one, is
-                        // compared in full, the run's first position stands for all the shorter ones, and the walk
-                        // goes on from the link of the run's first position.  The same best match per run as the
-                        // link-by-link walk finds, in a sixteenth of the steps: such items get a quarter of the chain
-                        // budget and still reach four times as far (one 64 KiB unit of runs of up to 64 bytes of two
-                        // values: 46 -> 37 ms, 1.030 -> 1.009 x the reference's size under FIXED; up to 128 bytes of
-                        // four values: 37 -> 31 ms, 1.049 -> 1.003 x; with the whole budget 68 and 43 ms for 1.002 and
-                        // 1.006 x).
-                        uint32_t r_own = 0, sx = 0, rcx = 0;
-                        bool scan = false, run_item = false;
-                        if constexpr (THOROUGH && ZGPU_RUN_MODE) {
-                            if (p + 4 <= n && own.x == __builtin_amdgcn_alignbyte(own.x, own.x, 1u)) {
-                                uint32_t l = 0;  // how far the position matches itself one byte on
-                                for (;;) {
-                                    const uint32_t m = mlen16(ld16(ring, (pi + l) & (RING - 1)), ld16(ring, (pi + 1u + l) & (RING - 1)));
-                                    l += m;
-                                    if (m < 16u || l >= maxlen) break;
-                                }
-                                r_own = l + 1u < maxlen ? l + 1u : maxlen;
-                                if (r_own < ZGPU_RUN_MIN) r_own = 0;
-                            }
-                            // Only in items where half of the positions start sixteen bytes of a run or more: a wave runs
-                            // every path that one of its lanes takes, and these steps cost an item of a few short runs
-                            // (two values 90:10) three times its time for nothing.
-                            run_item = __builtin_popcountll(__ballot(r_own != 0u)) >= ZGPU_RUN_LANES;
-                            if (run_item) {
-                                walk_budget = walk_budget / ZGPU_RUN_BUDGET_DIV > 0 ? walk_budget / ZGPU_RUN_BUDGET_DIV : 1;
-                            } else {
-                                r_own = 0;
+                        if constexpr (THOROUGH && ZGPU_RUN_KEY) {
+                            if (blen >= 4u && blen < maxlen) {  // (the match one byte back)
+                                const uint32_t o = pi + blen - 3u;
+                                const uint32_t *w = (const uint32_t *)(ring + (o & (RING - 1) & ~3u));
+                                own_tail = __builtin_amdgcn_alignbyte(w[1], w[0], o & 3u);
                             }
                         }
                         // one candidate of this lane's walk; false: the walk is over
-                        auto candidate = [&](auto run_tag) -> bool {
-                            constexpr bool RUN = decltype(run_tag)::value;  // the item is mostly runs (see r_own)
-                            bool forced = false;
-                            if constexpr (RUN) {
-                                if (scan) {
-                                    // sixteen bytes in front of the scan's position: how many of them belong to the run
-                                    const uint32_t room = limit - ((p - sx) & 0xffffu);  // bytes in front of sx within the links' reach
-                                    const v4u v = ld16(ring, (sx - 16u) & (RING - 1));
-                                    const uint32_t x3 = v.w ^ own.x, x2 = v.z ^ own.x, x1 = v.y ^ own.x, x0 = v.x ^ own.x;
-                                    uint32_t t = x3 ? (uint32_t)__builtin_clz(x3) >> 3
-                                               : x2 ? 4u + ((uint32_t)__builtin_clz(x2) >> 3)
-                                               : x1 ? 8u + ((uint32_t)__builtin_clz(x1) >> 3)
-                                               : x0 ? 12u + ((uint32_t)__builtin_clz(x0) >> 3) : 16u;
-                                    const bool edge = t >= room;
-                                    t = edge ? room : t;
-                                    if (rcx < r_own && t >= r_own - rcx) {
-                                        // the run has a candidate with as much of it left as this position has: compared
-                                        // in full below, and the scan goes on from there for the run's start
-                                        c = (sx - (r_own - rcx)) & 0xffffu;
-                                        sx = c;
-                                        rcx = r_own;
-                                        forced = true;
-                                    } else if (t == 16u && !edge) {
-                                        sx = (sx - 16u) & 0xffffu;
-                                        rcx += 16u;
-                                        return true;
-                                    } else {
-                                        // the run's first position (or the last one within reach) stands for the shorter
-                                        // ones behind it; the walk goes on from its link
-                                        const uint32_t s0 = (sx - t) & 0xffffu, ls = rcx + t, ds = (p - s0) & 0xffffu;
-                                        const bool better = rcx < r_own && ls > blen;
-                                        blen = better ? ls : blen;
-                                        best_dist = better ? ds : best_dist;
-                                        own_tail = better ? own.x : own_tail;
-                                        scan = false;
-                                        if (edge || (better && ls >= (uint32_t)P.nice)) {
-                                            last = 0xffffu;
-                                            return false;
-                                        }
-                                        last = ds;
-                                        c = prevt[s0 & WMASK];
-                                        return true;
-                                    }
-                                }
-                            }
+                        auto candidate = [&]() -> bool {
                             const uint32_t dist = (p - c) & 0xffffu;
                             if (dist <= last || dist > limit) {
                                 last = 0xffffu;
@@ -1352,32 +1298,6 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             last = dist;
                             const uint32_t ci = c & (RING - 1);
                             const uint32_t nxt = prevt[c & WMASK];
-                            const uint32_t c_cur = c;
-                            if constexpr (RUN) {
-                                if (r_own && !forced) {
-                                    // the end of an earlier run: as many bytes of the value as the chains are keyed on
-                                    // (four to eight), then another -- told from the candidate's first twelve bytes
-                                    const uint32_t *w = (const uint32_t *)(ring + (ci & ~3u));
-                                    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-                                    const uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, ci & 3u) ^ own.x;
-                                    const uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, ci & 3u) ^ own.x;
-                                    const uint32_t x2 = __builtin_amdgcn_alignbyte(w3, w2, ci & 3u) ^ own.x;
-                                    const uint32_t lead = x0 ? (uint32_t)__builtin_ctz(x0) >> 3
-                                                        : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3)
-                                                        : x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3) : 12u;
-                                    if (lead >= 4u && lead < 12u) {  // (r_own is 16 at least)
-                                        const bool better = lead > blen;
-                                        blen = better ? lead : blen;
-                                        best_dist = better ? dist : best_dist;
-                                        own_tail = better ? own.x : own_tail;
-                                        scan = true;
-                                        sx = c_cur;
-                                        rcx = lead;
-                                        c = nxt;
-                                        return !(better && lead >= (uint32_t)P.nice);
-                                    }
-                                }
-                            }
                             if (THOROUGH) {
                                 // Only a longer match replaces the best so far (the walk goes from near to far and
                                 // the nearest of equals wins), and a longer one agrees with this position in the
@@ -1413,21 +1333,6 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             } else if (len > cmpmax) {
                                 len = cmpmax;
                             }
-                            if constexpr (RUN) {
-                                if (r_own && !forced) {
-                                    // what the compare says about the candidate's run: it ends after len bytes, or
-                                    // (the match ends with this position's run and the candidate's goes on) later
-                                    if (len >= 4u && len < r_own) {
-                                        scan = true;
-                                        sx = c_cur;
-                                        rcx = len;
-                                    } else if (len == r_own && r_own < maxlen && ring[(ci + r_own) & (RING - 1)] == (own.x & 0xffu)) {
-                                        scan = true;
-                                        sx = c_cur;
-                                        rcx = r_own + 1u;
-                                    }
-                                }
-                            }
                             c = nxt;
                             // selects, not a branch: every branch the wave can diverge on costs a
                             // handful of scalar instructions per candidate, and the scalar unit is
@@ -1450,23 +1355,16 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             // steps below look for longer ones)
                             return !(better && (len >= maxlen || len >= (uint32_t)P.nice));
                         };
-                        if (p + 4 <= n) {
+                        if (p + 4 <= n && !(THOROUGH && ZGPU_RUN_KEY && blen >= maxlen)) {
                             last = 0;
-                            if (THOROUGH && ZGPU_RUN_MODE && run_item) {
-                                // (a loop of its own: with the run steps in the one loop, items without runs took
-                                // half as long again for code they never reach)
-                                for (int budget = walk_budget; budget > 0; --budget)
-                                    if (!candidate(RunTag<THOROUGH && ZGPU_RUN_MODE>{})) break;
-                            } else {
-                                for (int budget = walk_budget; budget > 0; --budget) {
-                                    // two candidates in and not one position of the item (of those still walking) has
-                                    // found four bytes that repeat: incompressible data, whose chains hold hash
-                                    // collisions only -- the walk ends for the whole item (random units 56.6 -> 66.6
-                                    // GB/s; no named input and none of the bench's kinds changes size; ending after
-                                    // one candidate is no faster)
-                                    if (!THOROUGH && budget == walk_budget - 2 && !__ballot(blen >= 4u)) break;
-                                    if (!candidate(RunTag<false>{})) break;
-                                }
+                            for (int budget = walk_budget; budget > 0; --budget) {
+                                // two candidates in and not one position of the item (of those still walking) has
+                                // found four bytes that repeat: incompressible data, whose chains hold hash
+                                // collisions only -- the walk ends for the whole item (random units 56.6 -> 66.6
+                                // GB/s; no named input and none of the bench's kinds changes size; ending after
+                                // one candidate is no faster)
+                                if (!THOROUGH && budget == walk_budget - 2 && !__ballot(blen >= 4u)) break;
+                                if (!candidate()) break;
                             }
                             if constexpr (C::FULL_DISTANCE && ZGPU_FAR_BLOCK) {
                                 // A walk that ran out of the links' reach stands at a candidate that is still worth a
