@@ -158,7 +158,7 @@ int zgpu_set_long_match(int deep_chain, int probe_fans);
  * (1.03-1.47 x the reference's size under FIXED, up to 1.29 x under DYNAMIC at
  * the default max_chain).  Every unit of at least 4 KiB is therefore classified
  * on the device before it is searched, from 32 samples of 64 bytes: fewer than
- * 45 % of the samples are one value throughout (runs of hundreds of bytes need
+ * 60 % of the samples are one value throughout (runs of hundreds of bytes need
  * nothing more than the default search), and among the other samples two bytes
  * are equal with a chance of at least 0.155 (what six equally likely values
  * give; text: 0.05-0.08; 0.25 for a unit of more than eight values) or at

@@ -80,10 +80,11 @@ def _families():
         "runs <= 16 of 8": runs_of(8, 16),
         "runs <= 32 of 4": runs_of(4, 32),
         # (the positions of a run are keyed on its value and length: up to 64 bytes of two values was 1.02-1.035 x
-        # depending on the seed, up to 128 of four 1.05 x.  Up to 128 of two values -- which are runs of up to several
-        # hundred, as equal neighbours merge -- is past the class's limit on one-value samples: 1.08 x)
+        # depending on the seed, up to 128 of four 1.05 x, up to 128 of two -- which are runs of up to several
+        # hundred, as equal neighbours merge -- 1.08-1.12 x)
         "runs <= 64 of 2": runs_of(2, 64),
         "runs <= 128 of 4": runs_of(4, 128),
+        "runs <= 128 of 2": runs_of(2, 128),
         "16-bit samples below 6": np.stack([rng.integers(0, 6, n // 2).astype(np.uint8), np.zeros(n // 2, dtype=np.uint8)], 1).reshape(-1),
     }
 

@@ -2534,9 +2534,12 @@ zgpu_emit_slots_kernel(EParams P) {
 //     what six equally likely values give; seven give 0.143, text 0.05-0.08, which the default search
 //     serves within the bar -- or at least half of the sampled bytes equal their successor (runs of any
 //     number of values);
-//   * and fewer than 45 % of the chunks are one byte value throughout: runs of hundreds of bytes reach
-//     the maximum match length at the first candidates of their chains and need no second search (with
-//     run lengths up to 512 the share is 0.77 +- 0.07, up to 128 it is 0.25 +- 0.08).
+//   * and fewer than 60 % of the chunks are one byte value throughout: runs of hundreds of bytes reach
+//     the maximum match length at the first candidates of their chains and need no second search, which
+//     takes six times as long on them (runs of up to 512 bytes of four values, a tenth of the benchmark's
+//     units: the share is 0.77 +- 0.07 and never below 0.56 in 800 units; up to 128 bytes of two values,
+//     several hundred where equal neighbours merge: 0.5 +- 0.09, and 1.09-1.12 x the reference's size
+//     without the second search).
 // How many distinct byte values the sample holds decides how much the unit gets: up to eight, it is the kind
 // of data the pass is for; with more -- zeros and small numbers in the tables of a binary, spaces in indented
 // text -- half of the units of a shared library qualify, and they get a short second search only.
@@ -2550,7 +2553,7 @@ zgpu_emit_slots_kernel(EParams P) {
 #define ZGPU_DENSE_LONG_KEY 1
 #endif
 #ifndef ZGPU_CLS_ONE_VALUE_PCT
-#define ZGPU_CLS_ONE_VALUE_PCT 45u
+#define ZGPU_CLS_ONE_VALUE_PCT 60u
 #endif
 #define ZGPU_CLS_SAMPLES (64u * ZGPU_CLS_CHUNKS)
 extern "C" __global__ void __launch_bounds__(256)
