@@ -182,7 +182,7 @@ int zgpu_set_long_match(int deep_chain, int probe_fans);
  * keyed on value and run length), skewed two- and three-valued data 17-35 ms:
  * 0.5-15 GB/s per GPU, where one CPU core runs the reference's algorithm at
  * 0.3-1.6 MB/s; units of the short search take 1-2 ms; other input
- * pays the classification and one empty launch, 0.2 % of its time.  The
+ * pays the classification and one nearly empty launch, 0.2 % of its time.  The
  * second search runs beside the first, which passes those units over (the
  * first runs on a stream of the plan's own, forked from the caller's stream
  * and joined to it again before the output is written): a batch with a few

@@ -746,7 +746,8 @@ __device__ __forceinline__ void search_units(const Params &P) {
         const uint32_t ubyte = THOROUGH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[M_NEXT + 9]) : 0u;
         const uint32_t ucls = ubyte & 3u;
         // bytes five to eight of a position that go into its chain key besides the first four (none, one, two, four)
-        const uint32_t ukey = ubyte >> 4;
+        const uint32_t ukey = (ubyte >> 4) & 3u;
+        const bool key3 = (ubyte & 0x40u) != 0u;  // the chains are keyed on three bytes
         const uint32_t key_mask = ukey == 0u ? 0u : ukey == 1u ? 0xffu : ukey == 2u ? 0xffffu : 0xffffffffu;
         const int u_chain = !THOROUGH || !ucls ? P.max_chain : ucls == 1u ? P.class_chain[0] : ucls == 2u ? P.class_chain[1] : P.class_chain[2];
         const int u_lazy = !THOROUGH || !ucls ? P.lazy : ucls == 1u ? P.class_lazy[0] : ucls == 2u ? P.class_lazy[1] : P.class_lazy[2];
@@ -1125,6 +1126,12 @@ __device__ __forceinline__ void search_units(const Params &P) {
                             // candidate the walk must at least test; keyed on eight, a 256th, and the matches that
                             // such data has are longer than eight bytes anyway.  The bytes past the unit's end are
                             // not part of a key.
+                            // Units of many byte values of which a few weigh heavily (the tables of a binary: 16-bit
+                            // values in 32-bit slots, small numbers among zeros) are keyed on three bytes, as the
+                            // reference keys everything (src/rawdeflate.js:314-320): what repeats there is often three bytes long, and a chain
+                            // keyed on four never shows it (of 256 units of shared libraries, 5 were above 1.03 x the
+                            // reference's size under FIXED -- up to 1.09 x, at any chain budget -- and 1 is).
+                            if (key3 && !run_key) first4 &= 0xffffffu;
                             if (key_mask && !run_key && ip + 4 <= n) {
                                 const uint32_t left = n - ip - 4u;
                                 uint32_t next4 = __builtin_amdgcn_alignbyte(w[2], w[1], ip & 3u) & key_mask;
@@ -2549,6 +2556,12 @@ zgpu_emit_slots_kernel(EParams P) {
 #define ZGPU_CLS_CHUNKS 32
 #define ZGPU_CLS_MAX_VALUES 8u
 #define ZGPU_CLS_MIN_BYTES 4096u
+// units of the third class with more than this many byte values in the sample are keyed on three bytes (a skewed
+// alphabet of eight or sixteen values is not: its three-byte chains are all short matches, and the sixty-four
+// nearest of them hide the long ones -- 1.02 -> 1.05 x the reference's size)
+#ifndef ZGPU_DENSE_KEY3_VALUES
+#define ZGPU_DENSE_KEY3_VALUES 16u
+#endif
 #ifndef ZGPU_DENSE_LONG_KEY
 #define ZGPU_DENSE_LONG_KEY 1
 #endif
@@ -2625,7 +2638,7 @@ zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_fi
             key_code = len >= 8.0f ? 3u : len >= 6.0f ? 2u : len >= 5.0f ? 1u : 0u;
         }
         // the first search passes the unit over; the second reads its class (and key length) here
-        taken[u] = (uint8_t)(1u + which + (key_code << 4));
+        taken[u] = (uint8_t)(1u + which + (key_code << 4) + (which == 2u && values > ZGPU_DENSE_KEY3_VALUES ? 0x40u : 0u));
     }
 }
 
