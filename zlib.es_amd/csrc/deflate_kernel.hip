@@ -650,6 +650,13 @@ struct Params {
 #ifndef ZGPU_RUN_KEY
 #define ZGPU_RUN_KEY 1
 #endif
+// The same keys in the first search, for units that are not of the dense class but have a quarter of their bytes
+// equal to their successor (indented text).  Measured and left off: of 115 units of indented JSON, 16 are above
+// 1.03 x the reference's size under FIXED without and 12 with, the sums of six sets of real files gain 0.05 %,
+// and the bench, none of whose units is flagged, loses 1.4 %.
+#ifndef ZGPU_FIRST_RUN_KEY
+#define ZGPU_FIRST_RUN_KEY 0
+#endif
 template <bool THOROUGH, class C>
 __device__ __forceinline__ void search_units(const Params &P) {
     // the variant's geometry; these names shadow the full-window constants of the same name
@@ -696,7 +703,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
         for (;;) {
             const uint32_t ticket = atomicAdd(P.counter, 1u);
             nu = P.unit_list ? (ticket < P.list_len ? P.unit_list[ticket] : 0xffffffffu) : P.unit_first + ticket;
-            if (nu >= P.unit_end || !P.skip || !P.skip[nu]) break;
+            if (nu >= P.unit_end || !P.skip || !(P.skip[nu] & 3u)) break;
         }
         uint64_t uo = 0, to = 0;
         uint32_t nn = 0, prm = 0, bf = 0;
@@ -716,6 +723,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
         misc[M_NEXT + 6] = (uint32_t)(to >> 32);
         misc[M_NEXT + 7] = bf;
         if (THOROUGH) misc[M_NEXT + 9] = P.unit_class && nu < P.unit_end ? P.unit_class[nu] : 0u;
+        else if (ZGPU_FIRST_RUN_KEY) misc[M_NEXT + 9] = P.skip && nu < P.unit_end ? P.skip[nu] : 0u;
         asm volatile("" ::: "memory");
         lds_st(&misc[M_NEXT + 8], tag);  // the entries above are complete (LDS stores land in order)
     };
@@ -743,7 +751,9 @@ __device__ __forceinline__ void search_units(const Params &P) {
         uint16_t *tokbuf = P.tok + ((uint64_t)misc[M_NEXT + 5] | (uint64_t)misc[M_NEXT + 6] << 32);  // of the block in progress
         const uint32_t unit_blk_first = misc[M_NEXT + 7];
         // chain budget and lazy value of this unit: the launch's, or (second search) those of the unit's class
-        const uint32_t ubyte = THOROUGH ? (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[M_NEXT + 9]) : 0u;
+        const uint32_t ubyte = THOROUGH || ZGPU_FIRST_RUN_KEY ? (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[M_NEXT + 9]) : 0u;
+        // positions of runs are keyed on (value, run length): always in the thorough variant, else where the unit's class byte says so
+        const bool run_keys = THOROUGH || (ZGPU_FIRST_RUN_KEY && (ubyte & 0x80u) != 0u);
         const uint32_t ucls = ubyte & 3u;
         // bytes five to eight of a position that go into its chain key besides the first four (none, one, two, four)
         const uint32_t ukey = (ubyte >> 4) & 3u;
@@ -1089,7 +1099,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                         const uint32_t *w = (const uint32_t *)(ring + (ip & (RING - 1) & ~3u));
                         uint32_t first4 = __builtin_amdgcn_alignbyte(w[1], w[0], ip & 3u);
                         bool run_key = false;
-                        if constexpr (THOROUGH && ZGPU_RUN_KEY) {
+                        if (ZGPU_RUN_KEY && (THOROUGH || ZGPU_FIRST_RUN_KEY) && run_keys) {
                             // A position that starts eight or more bytes of one value is keyed on the value and on how
                             // many bytes of it there are (up to 258).  Keyed on its first bytes it shares a chain with
                             // every position of every run of the value, hundreds to thousands of them; of a run's
@@ -1270,7 +1280,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                     // (incrementing-run units: sizes +0.1 %).  Only with the deep walk on: without it those positions
                     // are where the parse lands after a match that was cut short.
                     int walk_budget = u_chain;
-                    if constexpr (THOROUGH && ZGPU_RUN_KEY) {
+                    if (ZGPU_RUN_KEY && (THOROUGH || ZGPU_FIRST_RUN_KEY) && run_keys) {
                         // (see the chain keys of positions inside runs) the match one byte back, for the whole item
                         if (__ballot(p + 4 <= n && own.x == __builtin_amdgcn_alignbyte(own.x, own.x, 1u))) score_distance(1u);
                     }
@@ -2639,6 +2649,8 @@ zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_fi
         }
         // the first search passes the unit over; the second reads its class (and key length) here
         taken[u] = (uint8_t)(1u + which + (key_code << 4) + (which == 2u && values > ZGPU_DENSE_KEY3_VALUES ? 0x40u : 0u));
+    } else if (ZGPU_FIRST_RUN_KEY && live && lane == 0 && equal * 4u >= used && one_value * 100u < 30u * ZGPU_CLS_CHUNKS) {
+        taken[u] = 0x80u;  // not of the class, but a quarter of its bytes equal their successor (indented text)
     }
 }
 
