@@ -287,7 +287,7 @@ def make_workload(ctx, workload, short):
                           "files_per_gpu": nf, "max_file_bytes": mx}
     if workload == "fewvalues":
         # units of two to six equally likely byte values: the content the bounded search cannot serve and the
-        # library's dense-class pass is for (every unit is classified on the device and searched a second time)
+        # library's dense-class pass is for (every unit is classified on the device and searched by the thorough variant)
         nu, ub = args.units or 512, args.unit_bytes or 65536
         g = torch.Generator(device=dev)
         g.manual_seed(seed ^ 0xFE)

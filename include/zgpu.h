@@ -163,10 +163,13 @@ int zgpu_set_long_match(int deep_chain, int probe_fans);
  * are equal with a chance of at least 0.155 (what six equally likely values
  * give; text: 0.05-0.08; 0.25 for a unit of more than eight values) or at
  * least half of the bytes equal their successor.  The units of that class are
- * searched a second time the reference's way (src/rawdeflate.js:370-395: every
+ * searched the reference's way instead (src/rawdeflate.js:370-395: every
  * candidate compared to its full length, the longest wins, the nearest among
  * equals), along at most max_chain candidates per position (0..32768, default
- * 2048; 0 = no such pass).  Units of more than eight byte values -- zeros and
+ * 2048; 0 = no such pass), on hash chains keyed to suit the content: the
+ * positions of a run of one value on the value and the run's length, units of
+ * at most six values on five to eight bytes instead of four, tables of many
+ * values on three like the reference's.  Units of more than eight byte values -- zeros and
  * small numbers in the tables of a binary: half of the units of a shared
  * library qualify -- get a thirty-second of that: 64 candidates buy them 3 % of
  * size under FIXED for half as much time again, where the whole budget buys
