@@ -3,7 +3,6 @@
 under a directory (argument) (default: the ROCm libraries of the image, GPU code objects and x86 code), 64 KiB units,
 DYNAMIC and FIXED, every unit verified by the GPU inflate verifier.  Prints speed, size and what the
 dense-class pass took (by running once more with the pass off)."""
-import glob
 import os
 import sys
 import time
@@ -18,7 +17,6 @@ import _gpu_verify as gv  # noqa: E402
 import zlib_es_amd as z  # noqa: E402
 
 root = sys.argv[1] if len(sys.argv) > 1 else "/opt/rocm/lib"
-pattern = root
 limit = int(float(os.environ.get("GIB", "2")) * (1 << 30))
 ub = 65536
 buf = np.empty(limit, dtype=np.uint8)
@@ -45,7 +43,7 @@ nu = have // ub
 dev = torch.device("cuda")
 data = torch.from_numpy(buf[: nu * ub]).to(dev)
 off = np.arange(nu + 1, dtype=np.uint64) * np.uint64(ub)
-print("%d units of 64 KiB from %s" % (nu, pattern), flush=True)
+print("%d units of 64 KiB from %s" % (nu, root), flush=True)
 for ctype in (2, 1):
     sizes = {}
     for dense in (1, 0):
