@@ -298,7 +298,10 @@ uint64_t zgpu_plan_out_bound(const zgpu_plan *plan);
  * owns, forked from `stream` by an event after the call's first kernels and
  * joined to it by another before its last: whatever the caller enqueues on
  * `stream` after the call is ordered after all of it, as if the plan used
- * `stream` alone.  One run of a plan at a time (its workspace is one). */
+ * `stream` alone.  One run of a plan at a time (its workspace is one).  The
+ * call allocates nothing and waits for nothing: it may be captured in a HIP
+ * graph (the plan's stream joins the capture through the fork event) and
+ * replayed; zgpu_plan_fetch after a replay reads that replay's results. */
 int zgpu_plan_run(zgpu_plan *plan, const void *d_in, void *d_out, uint64_t out_cap, void *stream);
 /* Device-side results of the last run (valid once the stream has drained):
  * out_off: n_units+1 x uint64, crc/adler: n_units x uint32 (zero unless
