@@ -156,7 +156,7 @@ int zgpu_set_long_match(int deep_chain, int probe_fans);
  * the longest of them is a few bytes longer than the longest of the nearest
  * max_chain -- at every position, which no bounded walk makes up for
  * (1.03-1.47 x the reference's size under FIXED, up to 1.29 x under DYNAMIC at
- * the default max_chain).  Every unit of at least 4 KiB is therefore classified
+ * the default max_chain).  Every unit of at least 256 bytes is therefore classified
  * on the device before it is searched, from 32 samples of 64 bytes: fewer than
  * 60 % of the samples are one value throughout (runs of hundreds of bytes need
  * nothing more than the default search), and among the other samples two bytes

@@ -2565,7 +2565,9 @@ zgpu_emit_slots_kernel(EParams P) {
 // on long runs: a batch of such units took 300 ms instead of 24 when they were counted in).
 #define ZGPU_CLS_CHUNKS 32
 #define ZGPU_CLS_MAX_VALUES 8u
-#define ZGPU_CLS_MIN_BYTES 4096u
+// (4096 for most of the round: two-valued files of 300-4000 bytes then came out at 1.07-1.20 x the reference's
+// size under FIXED; classified, at 1.005-1.016 x.  The samples of a unit shorter than 2 KiB overlap.)
+#define ZGPU_CLS_MIN_BYTES 256u
 // units of the third class with more than this many byte values in the sample are keyed on three bytes (a skewed
 // alphabet of eight or sixteen values is not: its three-byte chains are all short matches, and the sixty-four
 // nearest of them hide the long ones -- 1.02 -> 1.05 x the reference's size)
