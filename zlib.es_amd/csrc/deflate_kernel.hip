@@ -2574,6 +2574,9 @@ zgpu_emit_slots_kernel(EParams P) {
 #ifndef ZGPU_DENSE_KEY3_VALUES
 #define ZGPU_DENSE_KEY3_VALUES 16u
 #endif
+#ifndef ZGPU_DENSE_KEY3_BELOW
+#define ZGPU_DENSE_KEY3_BELOW 3.5f
+#endif
 #ifndef ZGPU_DENSE_LONG_KEY
 #define ZGPU_DENSE_LONG_KEY 1
 #endif
@@ -2583,7 +2586,7 @@ zgpu_emit_slots_kernel(EParams P) {
 #define ZGPU_CLS_SAMPLES (64u * ZGPU_CLS_CHUNKS)
 extern "C" __global__ void __launch_bounds__(256)
 zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_first, uint32_t unit_end,
-                     uint32_t *dense_list, uint32_t *dense_count, uint8_t *taken) {
+                     uint32_t *dense_list, uint32_t *dense_count, uint8_t *taken, uint32_t fixed_codes) {
     __shared__ uint32_t count[4][256];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const uint32_t u = unit_first + blockIdx.x * 4u + w;
@@ -2648,6 +2651,12 @@ zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_fi
             const float window = un < 32768ull ? (float)un : 32768.0f;
             const float len = __logf(window * (1.0f / 32.0f)) / -__logf(q < 0.999f ? q : 0.999f);
             key_code = len >= 8.0f ? 3u : len >= 6.0f ? 2u : len >= 5.0f ? 1u : 0u;
+            // ... and three where even four leave too few -- small files, or five and six values in a few KiB: the
+            // reference keys on three (src/rawdeflate.js:314-320) and a file of 300-3000 bytes lives on its three-byte
+            // matches (five values in 1000 bytes: 1.06 x the reference's size under FIXED keyed on four, 1.000 x on
+            // three).  Under FIXED only: with DYNAMIC codes the same files are 4-8 % *smaller* than the reference's
+            // without those matches, and equal to it with them.
+            if (fixed_codes && len < ZGPU_DENSE_KEY3_BELOW) key_code = 4u;  // (bit 6 of the byte)
         }
         // the first search passes the unit over; the second reads its class (and key length) here
         taken[u] = (uint8_t)(1u + which + (key_code << 4) + (which == 2u && values > ZGPU_DENSE_KEY3_VALUES ? 0x40u : 0u));

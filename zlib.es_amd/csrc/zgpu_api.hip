@@ -1446,7 +1446,8 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
                 HIPCHK(hipMemsetAsync(p->b_taken.as<uint8_t>() + first, 0, cnt, st));
                 hipLaunchKernelGGL(zgpu_classify_kernel, dim3((cnt + 3) / 4), dim3(256), 0, st, (const uint8_t *)d_in,
                                    p->d_in_off, first, end, p->b_dense.as<uint32_t>(),
-                                   p->d_counter() + 6 * p->rounds.size() + 1, p->b_taken.as<uint8_t>());
+                                   p->d_counter() + 6 * p->rounds.size() + 1, p->b_taken.as<uint8_t>(),
+                                   p->ctype == ZGPU_FIXED ? 1u : 0u);
             }
             P.skip = p->dense_cap ? p->b_taken.as<uint8_t>() : nullptr;
             hipStream_t fs = st;  // the stream of the first search
