@@ -266,3 +266,20 @@ def test_small_files_of_few_values_meet_the_bar(z):
         assert got <= RATIO_BAR * ref, (ctype, got / ref)
         worst = max(sizes[i] / len(zo.rawdeflate(datas[i], ctype)) for i in dense)
         assert worst <= 1.05, (ctype, worst)
+
+
+def test_small_real_files_under_fixed(z):
+    # sixteen C headers of the image cut to 1000 and to 3000 bytes: under FIXED every one was above 1.03 x the
+    # reference's size at 1000 bytes (worst 1.045 x) and seven at 3000 while their chains were keyed on four bytes --
+    # a small file lives on its three-byte matches, and the reference keys on three (src/rawdeflate.js:314-320)
+    import glob
+    import os
+    files = [f for f in sorted(glob.glob("/usr/include/*.h")) if os.path.isfile(f) and os.path.getsize(f) >= 3000][:16]
+    if len(files) < 8:
+        pytest.skip("no C headers on this box")
+    for n in (1000, 3000):
+        datas = [np.fromfile(f, dtype=np.uint8, count=n) for f in files]
+        for ctype in (1, 2):
+            sizes = _sizes(z, datas, ctype)
+            ratios = [s / len(zo.rawdeflate(d, ctype)) for s, d in zip(sizes, datas)]
+            assert max(ratios) <= RATIO_BAR, (n, ctype, max(ratios))

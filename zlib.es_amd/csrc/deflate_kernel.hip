@@ -634,6 +634,7 @@ struct Params {
     uint32_t list_len;
     const uint32_t *unit_prime; // per unit: bytes before it (same stream, multiple of 64, <= 32 KiB) that prime its window
     const uint8_t *skip;        // NULL, or per unit: not zero = another launch searches this unit, pass it over
+    uint32_t key3_max_bytes;    // first search: units of at most this many bytes are keyed on three bytes (0: none)
     const uint8_t *unit_class;  // NULL, or per unit (thorough variant): class 1..3 of a unit picks its chain budget
     int class_chain[3];         //   and its lazy value from these instead of max_chain and lazy
     int class_lazy[3];
@@ -754,6 +755,15 @@ __device__ __forceinline__ void search_units(const Params &P) {
         const uint32_t ubyte = THOROUGH || ZGPU_FIRST_RUN_KEY ? (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[M_NEXT + 9]) : 0u;
         // positions of runs are keyed on (value, run length): always in the thorough variant, else where the unit's class byte says so
         const bool run_keys = THOROUGH || (ZGPU_FIRST_RUN_KEY && (ubyte & 0x80u) != 0u);
+        // A small unit under FIXED is keyed on three bytes like the reference's (src/rawdeflate.js:314-320): in a window
+        // of a few KiB a chain is short however it is keyed, and the three-byte matches that a four-byte key hides are
+        // worth 2-4 % of such a file (C headers cut to 1000 bytes: all of 16 above 1.03 x the reference's size, worst
+        // 1.045 x).  In a full window the same key fills the walk's eight steps with short matches (+2 % on the bench
+        // mix), and under DYNAMIC small files are 1-2 % smaller than the reference's without those matches.
+        // (in the variants that serve small units: the full-window kernel is the same code with or without this)
+        const bool key3_first = !THOROUGH && C::WG_PER_CU > 1 && n_unit <= P.key3_max_bytes;
+        const uint32_t first_key_mask = key3_first ? 0xffffffu : 0xffffffffu;
+        const uint32_t min_found = key3_first ? 3u : 4u;
         const uint32_t ucls = ubyte & 3u;
         // bytes five to eight of a position that go into its chain key besides the first four (none, one, two, four)
         const uint32_t ukey = (ubyte >> 4) & 3u;
@@ -1149,6 +1159,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                                 first4 ^= next4 * 0x2545F491u;
                             }
                         }
+                        if (!THOROUGH && C::WG_PER_CU > 1) first4 &= first_key_mask;
                         if (ip + 4 <= n) key = (hash4<HBITS>(first4) << 6) | (uint32_t)lane;  // all four bytes inside the unit
                     }
                     key = wave_sort64(key);
@@ -1380,7 +1391,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
                                 // collisions only -- the walk ends for the whole item (random units 56.6 -> 66.6
                                 // GB/s; no named input and none of the bench's kinds changes size; ending after
                                 // one candidate is no faster)
-                                if (!THOROUGH && budget == walk_budget - 2 && !__ballot(blen >= 4u)) break;
+                                if (!THOROUGH && budget == walk_budget - 2 && !__ballot(blen >= min_found)) break;
                                 if (!candidate()) break;
                             }
                             if constexpr (C::FULL_DISTANCE && ZGPU_FAR_BLOCK) {
