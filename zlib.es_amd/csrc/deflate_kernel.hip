@@ -724,7 +724,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
         misc[M_NEXT + 6] = (uint32_t)(to >> 32);
         misc[M_NEXT + 7] = bf;
         if (THOROUGH) misc[M_NEXT + 9] = P.unit_class && nu < P.unit_end ? P.unit_class[nu] : 0u;
-        else if (ZGPU_FIRST_RUN_KEY) misc[M_NEXT + 9] = P.skip && nu < P.unit_end ? P.skip[nu] : 0u;
+        else if (ZGPU_FIRST_RUN_KEY || C::WG_PER_CU > 1) misc[M_NEXT + 9] = P.skip && nu < P.unit_end ? P.skip[nu] : 0u;
         asm volatile("" ::: "memory");
         lds_st(&misc[M_NEXT + 8], tag);  // the entries above are complete (LDS stores land in order)
     };
@@ -752,7 +752,7 @@ __device__ __forceinline__ void search_units(const Params &P) {
         uint16_t *tokbuf = P.tok + ((uint64_t)misc[M_NEXT + 5] | (uint64_t)misc[M_NEXT + 6] << 32);  // of the block in progress
         const uint32_t unit_blk_first = misc[M_NEXT + 7];
         // chain budget and lazy value of this unit: the launch's, or (second search) those of the unit's class
-        const uint32_t ubyte = THOROUGH || ZGPU_FIRST_RUN_KEY ? (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[M_NEXT + 9]) : 0u;
+        const uint32_t ubyte = THOROUGH || ZGPU_FIRST_RUN_KEY || C::WG_PER_CU > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)misc[M_NEXT + 9]) : 0u;
         // positions of runs are keyed on (value, run length): always in the thorough variant, else where the unit's class byte says so
         const bool run_keys = THOROUGH || (ZGPU_FIRST_RUN_KEY && (ubyte & 0x80u) != 0u);
         // A small unit under FIXED is keyed on three bytes like the reference's (src/rawdeflate.js:314-320): in a window
@@ -761,7 +761,9 @@ __device__ __forceinline__ void search_units(const Params &P) {
         // 1.045 x).  In a full window the same key fills the walk's eight steps with short matches (+2 % on the bench
         // mix), and under DYNAMIC small files are 1-2 % smaller than the reference's without those matches.
         // (in the variants that serve small units: the full-window kernel is the same code with or without this)
-        const bool key3_first = !THOROUGH && C::WG_PER_CU > 1 && n_unit <= P.key3_max_bytes;
+        // (under DYNAMIC, P.key3_max_bytes is 0 and the unit's class byte asks for it: small units that look like the
+        // tables of a binary -- see the classifier)
+        const bool key3_first = !THOROUGH && C::WG_PER_CU > 1 && (n_unit <= P.key3_max_bytes || (ubyte & 0x08u) != 0u);
         const uint32_t first_key_mask = key3_first ? 0xffffffu : 0xffffffffu;
         const uint32_t min_found = key3_first ? 3u : 4u;
         const uint32_t ucls = ubyte & 3u;
@@ -2588,6 +2590,9 @@ zgpu_emit_slots_kernel(EParams P) {
 #ifndef ZGPU_DENSE_KEY3_BELOW
 #define ZGPU_DENSE_KEY3_BELOW 3.5f
 #endif
+#ifndef ZGPU_CLS_TABLE_MAX_BYTES
+#define ZGPU_CLS_TABLE_MAX_BYTES 16384u
+#endif
 #ifndef ZGPU_DENSE_LONG_KEY
 #define ZGPU_DENSE_LONG_KEY 1
 #endif
@@ -2673,6 +2678,14 @@ zgpu_classify_kernel(const uint8_t *in, const uint64_t *in_off, uint32_t unit_fi
         taken[u] = (uint8_t)(1u + which + (key_code << 4) + (which == 2u && values > ZGPU_DENSE_KEY3_VALUES ? 0x40u : 0u));
     } else if (ZGPU_FIRST_RUN_KEY && live && lane == 0 && equal * 4u >= used && one_value * 100u < 30u * ZGPU_CLS_CHUNKS) {
         taken[u] = 0x80u;  // not of the class, but a quarter of its bytes equal their successor (indented text)
+    } else if (live && lane == 0 && !fixed_codes && un <= ZGPU_CLS_TABLE_MAX_BYTES && values > 16u &&
+               count[w][0] * 10u >= used) {
+        // Not of the class either, under DYNAMIC, small, of many byte values, and a tenth of the sample is the zero
+        // byte: the tables of a binary (16-bit values in 32-bit slots), whose repeats are three bytes long.  Its first
+        // search keys on three bytes, as all small units do under FIXED: slices of 3000-8000 bytes of shared libraries
+        // were 1.014-1.022 x the reference's size in sum, three of sixteen above 1.03 x, and are 1.000-1.002 x with
+        // none.  (Small text keyed that way comes out at the reference's size too -- but is 1-3 % smaller keyed on four.)
+        taken[u] = 0x08u;
     }
 }
 

@@ -425,6 +425,11 @@ const uint32_t kKey3Max = [] {
     const char *e = getenv("ZGPU_KEY3_MAX");
     return e ? (uint32_t)strtoul(e, nullptr, 10) : 16384u;
 }();
+// (ZGPU_KEY3_DYNAMIC=1: the same under DYNAMIC, for measurements)
+const bool kKey3Dynamic = [] {
+    const char *e = getenv("ZGPU_KEY3_DYNAMIC");
+    return e && e[0] == '1';
+}();
 const uint64_t kQuarterMax = [] {
     const char *e = getenv("ZGPU_QUARTER_MAX");
     return e ? strtoull(e, nullptr, 10) : 8192ull;
@@ -1444,7 +1449,7 @@ int zgpu_plan_run(zgpu_plan *p, const void *d_in, void *d_out, uint64_t out_cap,
             P.unit_prime = p->d_prime;
             P.prof = g_prof;
             P.unit_class = nullptr;
-            P.key3_max_bytes = p->ctype == ZGPU_FIXED ? kKey3Max : 0u;
+            P.key3_max_bytes = p->ctype == ZGPU_FIXED || kKey3Dynamic ? kKey3Max : 0u;
             for (int c = 0; c < 3; ++c) P.class_chain[c] = P.class_lazy[c] = 0;
             // one launch over the round's range, or one per size class over its list
             const auto &R = p->rounds[r];
