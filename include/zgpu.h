@@ -122,8 +122,14 @@ int zgpu_last_hip_error(void);
  * and the first candidate beyond that is still examined), and matches of three
  * bytes -- the chains are keyed by four -- are found where they repeat 4, 8 or
  * 12 bytes back (arrays of small numbers) or where a longer candidate happens
- * to lead to them; the reference's other three-byte matches are not (up to
- * 9 % of size under FIXED on tables of 16-bit values in 32-bit slots). */
+ * to lead to them; the reference's other three-byte matches are not, in a
+ * unit of more than 16 KiB that is not of the dense class (see
+ * zgpu_set_dense_search: its units of many byte values are keyed by three).
+ * Units of at most 16 KiB are keyed by three bytes, like the reference's,
+ * under FIXED -- a small file lives on its three-byte matches: 2-4 % of size --
+ * and under DYNAMIC where they look like the tables of a binary (many byte
+ * values, a tenth of them zero); other small units under DYNAMIC stay keyed by
+ * four, which makes them 1-7 % smaller than the reference's. */
 int zgpu_set_search(int max_chain, int nice_length);
 /* Long matches.  A position whose match reaches the 32-byte compare length and
  * does not merely continue its predecessor's match is where a parse may need
